@@ -1,0 +1,348 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950 (MI355X).
+//
+//   C[m][n] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// This one kernel family carries >97 % of the FLOPs of the CLIP hot path:
+// the QKV / out-proj / MLP projections of every ResidualAttentionBlock (the `nn.Linear` /
+// `nn.MultiheadAttention` matmuls inside the third-party `clip` package that
+// /root/reference/CLIP/train.py:161 reaches through `model(image, text)`), their dgrad/wgrad
+// in backward, the prefix mapper (/root/reference/CLIP_prefix_caption/train.py:110-123) and the
+// GPT-2 Conv1D projections + lm_head (train.py:268).
+//
+// Operand layouts (per operand, template parameter *_KC = "contraction index contiguous"):
+//   A_KC=1: A(m,k) at A[m*lda + k]   (activations [M,K])
+//   A_KC=0: A(m,k) at A[k*lda + m]   (wgrad: dY^T, contraction over tokens)
+//   B_KC=1: B(n,k) at B[n*ldb + k]   (nn.Linear weight [N,K]; forward)
+//   B_KC=0: B(n,k) at B[k*ldb + n]   (dgrad through an [N,K] weight; GPT-2 Conv1D [K,N]; wgrad X)
+// so forward = (1,1), dgrad = (1,0), wgrad = (0,0): no transposed weight copies exist anywhere.
+//
+// Structure: 128x128x64 tile, 256 threads = 4 waves (2 x 2), each wave a 64x64 sub-tile as 4x4
+// v_mfma_f32_16x16x32_bf16.  Operand tiles go HBM -> LDS by global_load_lds_dwordx4 (16 B/lane,
+// no VGPR round trip) into two LDS buffers; one barrier per K-tile, the next tile's DMA is issued
+// before the current tile's MFMAs.  LDS images are lane-linear (a DMA requirement) and
+// XOR-swizzled through the *source* address so that fragment reads are bank-conflict free:
+//   K-contiguous tile  [128 rows][8 chunks of 16 B]:  chunk' = chunk ^ (row & 7), ds_read_b128
+//   K-strided tile     [64 k-rows][16 chunks]:        chunk' = chunk ^ ((kr&3)<<2 | (kr>>2)&3),
+//                                                     read with ds_read_b64_tr_b16 (HW transpose)
+// The MFMA is issued "swapped" (weights as the A operand): the accumulator then holds 4
+// consecutive n per lane, and with the n-permutation P() below each lane owns two runs of 8
+// consecutive output columns -> 16-byte stores, bias/residual/aux read as 16/32-byte vectors.
+#include "cclip_common.h"
+#include "../../include/cclip_hip.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (128 * 64 * 2)        // 16 KiB per operand tile
+#define STAGE_BYTES (2 * TILE_BYTES)     // A + B
+#define LDS_BYTES (2 * STAGE_BYTES)      // double buffered = 64 KiB -> 2 blocks / CU
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0, 0, 0, 0};
+
+struct GemmArgs {
+  const bf16* A; const bf16* B;
+  long lda, ldb;
+  int M, N, K;
+  int ktiles_per_split;
+  float alpha;
+  const float* bias;
+  const float* residual; long ldr;
+  const bf16* aux; long ldaux;
+  float* out_f32; bf16* out_bf16; bf16* out_pre; long ldc;
+  int act;
+  float* split_ws;   // != nullptr: raw fp32 partial tile stores to split_ws[z][M][N]
+};
+
+// n-permutation: position i (0..15) of MFMA n-tile nt (0..3) of a wave's 64-column block maps to
+// local column P = 8*(i>>2) + 32*(nt>>1) + 4*(nt&1) + (i&3).  With the accumulator map
+// (row = 4*(lane>>4) + reg) a lane then holds columns 8g..8g+7 (nt = 0,1) and 32+8g..32+8g+7
+// (nt = 2,3) of its block.
+__device__ __forceinline__ int nperm(int nt, int i) {
+  return 8 * (i >> 2) + 32 * (nt >> 1) + 4 * (nt & 1) + (i & 3);
+}
+__device__ __forceinline__ int fswz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
+
+// ---- staging: one 16 KiB operand tile = 16 wave-instructions of 1 KiB; wave w issues 4 ----
+// PERM: LDS row position rp of a K-contiguous tile holds tile row 64*(rp>>6) + nperm((rp>>4)&3, rp&15)
+// (free at staging time because the DMA source address is per lane), so fragment reads stay natural.
+template <int KC, int PERM>
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, long ld, int R, int Kend, int r0, int k0,
+                                           char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rb = wave * 4 + i;
+    const bf16* src;
+    if (KC) {
+      const int rp = rb * 8 + (lane >> 3);                  // LDS row position 0..127
+      const int c = (lane & 7) ^ (rp & 7);                  // logical 16-B chunk held at this LDS slot
+      int r = rp;
+      if (PERM) r = (rp & 64) + nperm((rp >> 4) & 3, rp & 15);
+      int gr = r0 + r; gr = gr < R ? gr : R - 1;            // clamp: rows past the edge are never stored
+      const int gk = k0 + c * 8;
+      src = G + (long)gr * ld + gk;
+      if (gk >= Kend) src = (const bf16*)g_zero16;
+    } else {
+      const int kr = rb * 4 + (lane >> 4);                  // k-row 0..63
+      const int c = (lane & 15) ^ fswz(kr);
+      int gc = r0 + c * 8; gc = gc <= R - 8 ? gc : R - 8;
+      const int gk = k0 + kr;
+      src = G + (long)gk * ld + gc;
+      if (gk >= Kend) src = (const bf16*)g_zero16;          // ragged contraction edge contributes zeros
+    }
+    glds16(src, lds_tile + rb * 1024);
+  }
+}
+
+// ---- fragment reads (lane l: index i = l&15 of the 16-wide tile, k-group g = l>>4: k = 32ks+8g+j) ----
+// K-contiguous tile, natural rows row0..row0+15.
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 15);
+  const int c = 4 * ks + (lane >> 4);
+  return *(const bf16x8*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+}
+// K-strided tile; the tile's 16 columns are given as four 4-column pieces: piece p starts at column col_of_piece(p).
+template <int PERM>
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int col0, int nt, int ks, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int col = PERM ? col0 + 8 * p + 32 * (nt >> 1) + 4 * (nt & 1) : col0 + 16 * nt + 4 * p;
+  const int chunk = col >> 3, sub = (col & 7) * 2;
+  const int kr0 = 32 * ks + 8 * g + q, kr1 = kr0 + 4;
+  bf16x4 lo = lds_read_tr16(tile + kr0 * 256 + ((chunk ^ fswz(kr0)) << 4) + sub);
+  bf16x4 hi = lds_read_tr16(tile + kr1 * 256 + ((chunk ^ fswz(kr1)) << 4) + sub);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v, float a) {
+  switch (ACT) {
+    case CCLIP_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
+    case CCLIP_ACT_TANH: return tanhf(v);
+    case CCLIP_ACT_GELU_NEW: {
+      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return 0.5f * v * (1.0f + tanhf(u));
+    }
+    case CCLIP_ACT_RELU: return fmaxf(v, 0.0f);
+    case CCLIP_ACT_DQUICKGELU: {   // v = upstream grad, a = saved pre-activation
+      const float s = 1.0f / (1.0f + __expf(-1.702f * a));
+      return v * s * (1.0f + 1.702f * a * (1.0f - s));
+    }
+    case CCLIP_ACT_DTANH: return v * (1.0f - a * a);   // a = saved tanh output
+    case CCLIP_ACT_DGELU_NEW: {
+      const float u = 0.7978845608028654f * (a + 0.044715f * a * a * a);
+      const float t = tanhf(u);
+      const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * a * a);
+      return v * (0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * du);
+    }
+    case CCLIP_ACT_DRELU: return a > 0.0f ? v : 0.0f;
+    default: return v;
+  }
+}
+
+template <int A_KC, int B_KC, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bm0 = (bid / tiles_n) * BM, bn0 = (bid % tiles_n) * BN;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt1 = (kt0 + p.ktiles_per_split < nkt) ? kt0 + p.ktiles_per_split : nkt;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (kt0 < kt1) {
+    stage_tile<A_KC, 0>(p.A, p.lda, p.M, p.K, bm0, kt0 * BK, smem, wave, lane);
+    stage_tile<B_KC, 1>(p.B, p.ldb, p.N, p.K, bn0, kt0 * BK, smem + TILE_BYTES, wave, lane);
+  }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    // every wave's DMA for tile kt has landed (vmcnt(0) is part of __syncthreads while a
+    // global_load_lds is outstanding) and every wave has finished reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < kt1) {
+      char* nb = smem + (cur ^ 1) * STAGE_BYTES;
+      stage_tile<A_KC, 0>(p.A, p.lda, p.M, p.K, bm0, (kt + 1) * BK, nb, wave, lane);
+      stage_tile<B_KC, 1>(p.B, p.ldb, p.N, p.K, bn0, (kt + 1) * BK, nb + TILE_BYTES, wave, lane);
+    }
+    const char* At = smem + cur * STAGE_BYTES;
+    const char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[4], wf[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        xf[mt] = A_KC ? frag_rows(At, wm0 + 16 * mt, ks, lane) : frag_cols<0>(At, wm0, mt, ks, lane);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        wf[nt] = B_KC ? frag_rows(Bt, wn0 + 16 * nt, ks, lane) : frag_cols<1>(Bt, wn0, nt, ks, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
+  const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = bm0 + wm0 + 16 * mt + li;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n0 = bn0 + wn0 + 32 * h + 8 * g;
+      if (m >= p.M || n0 >= p.N) continue;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
+      if (p.split_ws) {
+        float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        continue;
+      }
+      if (p.alpha != 1.0f) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+      }
+      if (p.bias) {
+        const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (p.out_pre) {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+        *(bf16x8*)(p.out_pre + (long)m * p.ldc + n0) = o;
+      }
+      if (ACT != CCLIP_ACT_NONE) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ACT >= CCLIP_ACT_DQUICKGELU) {
+          const bf16x8 ax = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n0);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) a[r] = (float)ax[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], a[r]);
+      }
+      if (p.residual) {
+        const float* rp = p.residual + (long)m * p.ldr + n0;
+        const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      if (p.out_f32) {
+        float* o = p.out_f32 + (long)m * p.ldc + n0;
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      if (p.out_bf16) {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+        *(bf16x8*)(p.out_bf16 + (long)m * p.ldc + n0) = o;
+      }
+    }
+  }
+}
+
+// ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
+                                                            float alpha, const float* __restrict__ residual, long ldr,
+                                                            float* __restrict__ out_f32, bf16* __restrict__ out_bf16, long ldc) {
+  const long total = (long)M * N / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float4 t = *(const float4*)(ws + ((long)z * M * N) + i * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+    const long m = (i * 4) / N, n = (i * 4) % N;
+    if (residual) {
+      const float4 r = *(const float4*)(residual + m * ldr + n);
+      s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+    }
+    if (out_f32) *(float4*)(out_f32 + m * ldc + n) = s;
+    if (out_bf16) {
+      bf16x4 o = {(bf16)s.x, (bf16)s.y, (bf16)s.z, (bf16)s.w};
+      *(bf16x4*)(out_bf16 + m * ldc + n) = o;
+    }
+  }
+}
+
+extern "C" int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream) {
+  if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return CCLIP_ERR_ARG;
+  if ((d->K & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
+  if (!d->a_kcontig && (d->M & 7)) return CCLIP_ERR_ARG;
+  if (!d->a_kcontig && d->b_kcontig) return CCLIP_ERR_ARG;   // (0,1) is not a layout this path uses
+  if ((uintptr_t)d->A & 15 || (uintptr_t)d->B & 15) return CCLIP_ERR_ARG;
+  if (d->residual && (d->ldr & 3)) return CCLIP_ERR_ARG;
+  if (d->aux && (d->ldaux & 7)) return CCLIP_ERR_ARG;
+  const bool is_bwd_act = d->act >= CCLIP_ACT_DQUICKGELU;
+  if (is_bwd_act && !d->aux) return CCLIP_ERR_ARG;
+  const int nkt = (d->K + BK - 1) / BK;
+  int splits = d->split_k > 1 ? d->split_k : 1;
+  if (splits > nkt) splits = nkt;
+  if (splits > 1 && !d->split_ws) return CCLIP_ERR_ARG;
+  if (splits > 1 && (d->bias || d->act != CCLIP_ACT_NONE || d->out_pre_bf16 || (d->N & 3))) return CCLIP_ERR_ARG;
+
+  GemmArgs a;
+  a.A = (const bf16*)d->A; a.B = (const bf16*)d->B; a.lda = d->lda; a.ldb = d->ldb;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.ktiles_per_split = (nkt + splits - 1) / splits;
+  splits = (nkt + a.ktiles_per_split - 1) / a.ktiles_per_split;   // no empty split
+  a.alpha = d->alpha; a.bias = d->bias; a.residual = d->residual; a.ldr = d->ldr;
+  a.aux = (const bf16*)d->aux; a.ldaux = d->ldaux;
+  a.out_f32 = d->out_f32; a.out_bf16 = (bf16*)d->out_bf16; a.out_pre = (bf16*)d->out_pre_bf16; a.ldc = d->ldc;
+  a.act = d->act; a.split_ws = splits > 1 ? d->split_ws : nullptr;
+
+  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+  dim3 grid(tiles, splits), block(256);
+  // instantiated (layout, activation) pairs = exactly the ones the hot path issues
+#define LAUNCH(AK, BKC, ACTV) hipLaunchKernelGGL((gemm_bf16_128<AK, BKC, ACTV>), grid, block, 0, stream, a)
+  const int lay = d->a_kcontig * 2 + d->b_kcontig;   // 3 = fwd, 2 = dgrad/Conv1D, 0 = wgrad
+  bool launched = true;
+  if (lay == 3) {
+    switch (d->act) {
+      case CCLIP_ACT_NONE: LAUNCH(1, 1, CCLIP_ACT_NONE); break;
+      case CCLIP_ACT_QUICKGELU: LAUNCH(1, 1, CCLIP_ACT_QUICKGELU); break;
+      case CCLIP_ACT_TANH: LAUNCH(1, 1, CCLIP_ACT_TANH); break;
+      case CCLIP_ACT_RELU: LAUNCH(1, 1, CCLIP_ACT_RELU); break;
+      case CCLIP_ACT_DGELU_NEW: LAUNCH(1, 1, CCLIP_ACT_DGELU_NEW); break;
+      default: launched = false;
+    }
+  } else if (lay == 2) {
+    switch (d->act) {
+      case CCLIP_ACT_NONE: LAUNCH(1, 0, CCLIP_ACT_NONE); break;
+      case CCLIP_ACT_GELU_NEW: LAUNCH(1, 0, CCLIP_ACT_GELU_NEW); break;
+      case CCLIP_ACT_DQUICKGELU: LAUNCH(1, 0, CCLIP_ACT_DQUICKGELU); break;
+      case CCLIP_ACT_DTANH: LAUNCH(1, 0, CCLIP_ACT_DTANH); break;
+      case CCLIP_ACT_DRELU: LAUNCH(1, 0, CCLIP_ACT_DRELU); break;
+      default: launched = false;
+    }
+  } else {
+    if (d->act == CCLIP_ACT_NONE) LAUNCH(0, 0, CCLIP_ACT_NONE); else launched = false;
+  }
+#undef LAUNCH
+  if (!launched) return CCLIP_ERR_ARG;
+  int st = cclip_launch_status();
+  if (st != CCLIP_OK) return st;
+  if (splits > 1) {
+    long total = (long)d->M * d->N / 4;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d->split_ws, splits, d->M, d->N,
+                       d->alpha, d->residual, d->ldr, d->out_f32, (bf16*)d->out_bf16, d->ldc);
+    st = cclip_launch_status();
+  }
+  return st;
+}

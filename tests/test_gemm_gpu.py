@@ -1,0 +1,142 @@
+"""GPU parity of the bf16 MFMA GEMM (cclip_gemm_bf16) against a plain torch fp32 matmul of the
+same bf16-rounded operands.  Tolerance: fp32 accumulation of exact bf16 products differs from
+torch's only by summation order -> 2e-3 relative to the row's |a|.|b| bound is generous; outputs
+rounded to bf16 get one extra 2^-8 relative rounding."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from cclip_hip import ops
+    return ops
+
+
+def _ref_act(v, act, aux):
+    import math
+    if act == 0:
+        return v
+    if act == 1:
+        return v * torch.sigmoid(1.702 * v)
+    if act == 2:
+        return torch.tanh(v)
+    if act == 3:
+        return 0.5 * v * (1 + torch.tanh(math.sqrt(2 / math.pi) * (v + 0.044715 * v ** 3)))
+    if act == 4:
+        return torch.relu(v)
+    a = aux.float()
+    if act == 16:
+        s = torch.sigmoid(1.702 * a)
+        return v * s * (1 + 1.702 * a * (1 - s))
+    if act == 17:
+        return v * (1 - a * a)
+    if act == 18:
+        a = a.clone().requires_grad_(True)
+        y = 0.5 * a * (1 + torch.tanh(math.sqrt(2 / math.pi) * (a + 0.044715 * a ** 3)))
+        (g,) = torch.autograd.grad(y.sum(), a)
+        return v * g
+    if act == 19:
+        return torch.where(a > 0, v, torch.zeros_like(v))
+    raise ValueError(act)
+
+
+def _report(name, got, ref, tol):
+    err = (got.float() - ref).abs()
+    scale = ref.abs().max().clamp_min(1e-6)
+    bad = err > tol * scale
+    if bad.any():
+        idx = bad.nonzero()[:8].tolist()
+        rows = bad.any(dim=1).nonzero().flatten()[:16].tolist()
+        cols = bad.any(dim=0).nonzero().flatten()[:16].tolist()
+        pytest.fail(f"{name}: {int(bad.sum())}/{bad.numel()} bad, max err {err.max().item():.4g} (scale {scale.item():.4g}); "
+                    f"first idx {idx}; bad rows {rows}; bad cols {cols}; got {got[idx[0][0], idx[0][1]].item()} ref {ref[idx[0][0], idx[0][1]].item()}")
+
+
+LAYOUTS = [(True, True), (True, False), (False, False)]
+SHAPES = [(128, 128, 64), (256, 384, 192), (450, 768, 768), (264, 200, 72), (1000, 2304, 768), (72, 136, 3072)]
+
+
+@pytest.mark.parametrize("akc,bkc", LAYOUTS)
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_plain(M, N, K, akc, bkc):
+    ops = _ops()
+    if not akc and M % 8:
+        pytest.skip("a_kcontig=0 needs M % 8 == 0")
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K) if akc else (K, M), device="cuda", generator=g).bfloat16()
+    B = torch.randn((N, K) if bkc else (K, N), device="cuda", generator=g).bfloat16()
+    Am = A.float() if akc else A.float().t()
+    Bm = B.float() if bkc else B.float().t()
+    ref = Am @ Bm.t()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16(A, B, a_kcontig=akc, b_kcontig=bkc, out_f32=out)
+    torch.cuda.synchronize()
+    _report(f"plain {M}x{N}x{K} {akc}{bkc}", out, ref, 2e-3)
+
+
+@pytest.mark.parametrize("act,akc,bkc", [(1, True, True), (2, True, True), (4, True, True), (18, True, True),
+                                         (3, True, False), (16, True, False), (17, True, False), (19, True, False)])
+def test_gemm_epilogues(act, akc, bkc):
+    ops = _ops()
+    M, N, K = 300, 264, 256
+    g = torch.Generator(device="cuda").manual_seed(act)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.1).bfloat16()
+    B = torch.randn((N, K) if bkc else (K, N), device="cuda", generator=g).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    aux = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    if act == 17:
+        aux = torch.tanh(aux.float()).bfloat16()
+    Bm = B.float() if bkc else B.float().t()
+    pre = 0.5 * (A.float() @ Bm.t()) + bias
+    ref = _ref_act(pre, act, aux) + res
+    out = torch.full((M, N), float("nan"), device="cuda")
+    outb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    outp = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_bf16(A, B, a_kcontig=akc, b_kcontig=bkc, alpha=0.5, bias=bias, act=act, aux=aux if act >= 16 else None,
+                  residual=res, out_f32=out, out_bf16=outb, out_pre=outp)
+    torch.cuda.synchronize()
+    _report(f"act{act} f32", out, ref, 2e-3)
+    _report(f"act{act} bf16", outb, ref, 1e-2)
+    _report(f"act{act} pre", outp, pre, 1e-2)
+
+
+def test_gemm_residual_inplace_and_ld():
+    """out_f32 aliases residual (x += ...), outputs with a row stride larger than N."""
+    ops = _ops()
+    M, N, K = 200, 128, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    B = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    big = torch.randn(M, 3 * N, device="cuda", generator=g)
+    x = big[:, N:2 * N]
+    ref = x.clone() + A.float() @ B.float().t()
+    ops.gemm_bf16(A, B, residual=x, out_f32=x)
+    torch.cuda.synchronize()
+    _report("inplace", x, ref, 2e-3)
+
+
+@pytest.mark.parametrize("splits", [2, 5, 16])
+def test_gemm_wgrad_splitk(splits):
+    """wgrad layout (0,0) with ragged contraction (tokens) and split-K slabs + accumulate into grad."""
+    ops = _ops()
+    T, N, K = 1000 + 8, 256, 384      # contraction = tokens
+    g = torch.Generator(device="cuda").manual_seed(splits)
+    dY = torch.randn(T, N, device="cuda", generator=g).bfloat16()
+    X = torch.randn(T, K, device="cuda", generator=g).bfloat16()
+    grad = torch.randn(N, K, device="cuda", generator=g)
+    ref = grad + dY.float().t() @ X.float()
+    ws = torch.empty(splits * N * K, device="cuda")
+    ops.gemm_bf16(dY, X, a_kcontig=False, b_kcontig=False, residual=grad, out_f32=grad, split_k=splits, split_ws=ws)
+    torch.cuda.synchronize()
+    _report(f"wgrad split{splits}", grad, ref, 2e-3)
+
+
+def test_gemm_bad_args_raise():
+    ops = _ops()
+    A = torch.zeros(64, 60, device="cuda", dtype=torch.bfloat16)   # K not a multiple of 8
+    B = torch.zeros(64, 60, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16(A, B, out_f32=out)
