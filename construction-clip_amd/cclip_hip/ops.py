@@ -94,3 +94,171 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     if split_k > 1:
         assert split_ws is not None and split_ws.numel() >= split_k * M * N and split_ws.dtype == torch.float32
     check(lib.cclip_gemm_bf16(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
+
+
+# --------------------------------------------------------------------------------------------
+# LayerNorm
+# --------------------------------------------------------------------------------------------
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows: int, row_index=None,
+                  out_bf16=None, out_f32=None, mean=None, rstd=None, eps: float = 1e-5) -> None:
+    _req(x, torch.float32, "x")
+    D = x.shape[-1]
+    out = out_bf16 if out_bf16 is not None else out_f32
+    check(lib.cclip_layernorm_fwd(_p(x), c_long(x.stride(-2)), _p(row_index), c_int(rows), c_int(D), _p(gamma), _p(beta),
+                                  c_float(eps), _p(out_bf16), _p(out_f32), c_long(out.stride(-2)), _p(mean), _p(rstd),
+                                  _stream()), "cclip_layernorm_fwd")
+
+
+def layernorm_bwd_ws_floats(rows: int, D: int) -> int:
+    return lib.cclip_layernorm_bwd_ws_floats(c_int(rows), c_int(D))
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, *,
+                  rows: int, row_index=None, dx_res=None, dx_out=None, dx_out_bf16=None, dgamma=None, dbeta=None,
+                  accumulate: bool = False, ws=None) -> None:
+    D = x.shape[-1]
+    dxo = dx_out if dx_out is not None else dx_out_bf16
+    lddx = dxo.stride(-2) if dxo is not None else x.stride(-2)
+    if dx_res is not None:
+        assert dx_res.stride(-2) == lddx
+    if dx_out is not None and dx_out_bf16 is not None:
+        assert dx_out.stride(-2) == dx_out_bf16.stride(-2)
+    check(lib.cclip_layernorm_bwd(_p(dy), c_int(int(dy.dtype == torch.bfloat16)), c_long(dy.stride(-2)), _p(x),
+                                  c_long(x.stride(-2)), _p(row_index), c_int(rows), c_int(D), _p(gamma), _p(mean),
+                                  _p(rstd), _p(dx_res), _p(dx_out), _p(dx_out_bf16), c_long(lddx), _p(dgamma),
+                                  _p(dbeta), c_int(int(accumulate)), _p(ws), _stream()), "cclip_layernorm_bwd")
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+class AttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p),
+        ("ldq", c_long), ("ldk", c_long), ("ldv", c_long),
+        ("o", c_void_p), ("ldo", c_long),
+        ("lse", c_void_p), ("key_keep", c_void_p),
+        ("B", c_int), ("T", c_int), ("H", c_int), ("head_dim", c_int), ("causal", c_int),
+        ("scale", c_float),
+        ("dout", c_void_p), ("lddo", c_long),
+        ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+        ("lddq", c_long), ("lddk", c_long), ("lddv", c_long),
+    ]
+
+
+def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale):
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        _req(t, torch.bfloat16, n)
+        assert t.stride(-1) == 1
+    d = AttnDesc()
+    d.q, d.k, d.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    d.ldq, d.ldk, d.ldv = q.stride(-2), k.stride(-2), v.stride(-2)
+    d.o, d.ldo = o.data_ptr(), o.stride(-2)
+    d.lse = 0 if lse is None else lse.data_ptr()
+    d.key_keep = 0 if key_keep is None else key_keep.data_ptr()
+    d.B, d.T, d.H, d.head_dim, d.causal = B, T, H, 64, int(causal)
+    d.scale = 0.125 if scale is None else scale
+    return d
+
+
+def attention_fwd(q, k, v, o, *, B: int, T: int, H: int, causal: bool = False, key_keep=None, lse=None, scale=None) -> None:
+    """q/k/v/o: bf16 2-D views [B*T, >= H*64] (any row stride, inner stride 1); head h at columns h*64.."""
+    d = _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale)
+    check(lib.cclip_attention_fwd(ctypes.byref(d), _stream()), "cclip_attention_fwd")
+
+
+def attention_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H: int, causal: bool = False, key_keep=None,
+                  scale=None) -> None:
+    d = _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale)
+    d.dout, d.lddo = dout.data_ptr(), dout.stride(-2)
+    d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.lddq, d.lddk, d.lddv = dq.stride(-2), dk.stride(-2), dv.stride(-2)
+    check(lib.cclip_attention_bwd(ctypes.byref(d), _stream()), "cclip_attention_bwd")
+
+
+# --------------------------------------------------------------------------------------------
+# exact fp32 GEMM:  C = alpha * A @ B^T-like contraction with arbitrary strides
+# --------------------------------------------------------------------------------------------
+def gemm_f32(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0) -> None:
+    """C[m,n] = alpha * sum_k A[m,k] * B[n,k] + beta*C.  A: [M,K], B: [N,K] as (possibly transposed) 2-D views."""
+    _req(A, torch.float32, "A"); _req(B, torch.float32, "B"); _req(C, torch.float32, "C")
+    M, K = A.shape
+    N, Kb = B.shape
+    assert K == Kb and C.shape == (M, N) and C.stride(1) == 1
+    check(lib.cclip_gemm_f32(_p(A), c_long(A.stride(0)), c_long(A.stride(1)), _p(B), c_long(B.stride(0)),
+                             c_long(B.stride(1)), c_int(M), c_int(N), c_int(K), c_float(alpha), c_float(beta), _p(C),
+                             c_long(C.stride(0)), _stream()), "cclip_gemm_f32")
+
+
+# --------------------------------------------------------------------------------------------
+# embeddings
+# --------------------------------------------------------------------------------------------
+def patchify(image: torch.Tensor, out_bf16: torch.Tensor, P: int) -> None:
+    _req(image, torch.float32, "image")
+    assert image.is_contiguous() and image.dim() == 4 and image.shape[1] == 3 and image.shape[2] == image.shape[3]
+    check(lib.cclip_patchify(_p(image), _p(out_bf16), c_int(image.shape[0]), c_int(image.shape[2]), c_int(P), _stream()),
+          "cclip_patchify")
+
+
+def vit_embed_ln(patch_out, cls, pos, gamma, beta, x, *, rows: int, T: int, x0=None, mean=None, rstd=None, eps=1e-5):
+    D = patch_out.shape[-1]
+    check(lib.cclip_vit_embed_ln(_p(patch_out), _p(cls), _p(pos), c_int(rows), c_int(T), c_int(D), _p(gamma), _p(beta),
+                                 c_float(eps), _p(x0), _p(x), _p(mean), _p(rstd), _stream()), "cclip_vit_embed_ln")
+
+
+def text_embed(text_i32, emb, pos, x, *, rows: int, L: int) -> None:
+    _req(text_i32, torch.int32, "text")
+    check(lib.cclip_text_embed(_p(text_i32), _p(emb), _p(pos), c_int(rows), c_int(L), c_int(emb.shape[1]),
+                               c_int(emb.shape[0]), _p(x), _stream()), "cclip_text_embed")
+
+
+def embed_scatter_add(text_i32, dx, demb, *, rows: int) -> None:
+    check(lib.cclip_embed_scatter_add(_p(text_i32), _p(dx), c_long(dx.stride(-2)), c_int(rows), c_int(demb.shape[1]),
+                                      c_int(demb.shape[0]), _p(demb), _stream()), "cclip_embed_scatter_add")
+
+
+def colsum_ws_floats(R: int, C: int) -> int:
+    return lib.cclip_colsum_ws_floats(c_int(R), c_int(C))
+
+
+def colsum(inp: torch.Tensor, out: torch.Tensor, ws: torch.Tensor, *, R: int, C: int, ld: int, accumulate: bool = False):
+    check(lib.cclip_colsum(_p(inp), c_int(int(inp.dtype == torch.bfloat16)), c_long(ld), c_int(R), c_int(C), _p(out),
+                           c_int(int(accumulate)), _p(ws), _stream()), "cclip_colsum")
+
+
+# --------------------------------------------------------------------------------------------
+# loss side
+# --------------------------------------------------------------------------------------------
+def l2norm_fwd(x, y, inv_norm) -> None:
+    check(lib.cclip_l2norm_fwd(_p(x), c_long(x.stride(0)), c_int(x.shape[0]), c_int(x.shape[1]), _p(y), c_long(y.stride(0)),
+                               _p(inv_norm), _stream()), "cclip_l2norm_fwd")
+
+
+def l2norm_bwd(dy, y, inv_norm, dx) -> None:
+    check(lib.cclip_l2norm_bwd(_p(dy), c_long(dy.stride(0)), _p(y), c_long(y.stride(0)), _p(inv_norm), c_int(y.shape[0]),
+                               c_int(y.shape[1]), _p(dx), c_long(dx.stride(0)), _stream()), "cclip_l2norm_bwd")
+
+
+def xent_rows(logits, labels_i32, *, loss_row=None, pred=None, dlogits=None, grad_scale: float = 1.0,
+              ignore_index: int = -100) -> None:
+    _req(logits, torch.float32, "logits"); _req(labels_i32, torch.int32, "labels")
+    R, C = logits.shape
+    check(lib.cclip_xent_rows(_p(logits), c_long(logits.stride(0)), c_int(R), c_int(C), _p(labels_i32), c_int(ignore_index),
+                              c_float(grad_scale), _p(loss_row), _p(pred), _p(dlogits),
+                              c_int(int(dlogits is not None and dlogits.dtype == torch.bfloat16)),
+                              c_long(0 if dlogits is None else dlogits.stride(0)), _stream()), "cclip_xent_rows")
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser / casts over flat buffers
+# --------------------------------------------------------------------------------------------
+def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr: float, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.0,
+               step: int = 1, correct_bias: bool = True, grad_scale: float = 1.0, mode: int = 0, bf16_shadow=None):
+    n = param.numel()
+    check(lib.cclip_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), c_long(n), c_float(lr), c_float(beta1),
+                               c_float(beta2), c_float(eps), c_float(weight_decay), c_int(step), c_int(int(correct_bias)),
+                               c_float(grad_scale), c_int(mode), _p(bf16_shadow), _stream()), "cclip_adamw_step")
+
+
+def cast_f32_to_bf16(src, dst) -> None:
+    check(lib.cclip_cast_f32_to_bf16(_p(src), _p(dst), c_long(src.numel()), _stream()), "cclip_cast_f32_to_bf16")

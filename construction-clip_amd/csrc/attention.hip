@@ -1,0 +1,321 @@
+// Fused multi-head attention (dh = 64, T <= 128) forward and backward for gfx950.
+//
+// Replaces the scaled-dot-product core of nn.MultiheadAttention inside the `clip` package's
+// ResidualAttentionBlock (image tower: T=50 no mask; text tower: T=77 additive causal mask),
+// reached from /root/reference/CLIP/train.py:161, and GPT-2's causal + key-padding attention
+// behind /root/reference/CLIP_prefix_caption/train.py:268.  The T x T score matrix never
+// touches HBM; forward keeps only the per-row log-sum-exp for backward.
+//
+// One workgroup (4 waves) per (batch, head).  K and V of the head live in LDS (<= 32 KiB), every
+// wave owns 16-query tiles.  All products are v_mfma_f32_16x16x32_bf16:
+//   forward  S^T = K Q^T   (keys on accumulator rows, query on the lane): row max / sum are
+//            in-lane + 2 shuffles, and the exponentiated accumulator IS the B operand of
+//            O^T = V^T P^T (contraction over its row index) - P never goes through LDS.
+//            V^T fragments come from ds_read_b64_tr_b16 (hardware transpose).
+//   backward S = Q K^T, dP = dO V^T (query on accumulator rows): P and dS are the B operands of
+//            dV^T = dO^T P and dK^T = Q^T dS with no data movement; only dS crosses LDS once,
+//            for dQ^T = K^T dS^T.  Each wave owns key tiles, so dK/dV need no cross-wave sums.
+// LDS images are [row][64] bf16 with 128-byte rows, 16-byte chunk c of row r stored at
+// chunk c ^ (r & 7): conflict-free for both ds_read_b128 row reads and the transposed reads.
+#include "cclip_common.h"
+#include "../../include/cclip_hip.h"
+
+struct AttnArgs {
+  const bf16* q; const bf16* k; const bf16* v;   // row (b*T + t), head h at column h*64
+  long ldq, ldk, ldv;
+  bf16* o; long ldo;
+  float* lse;                                     // [B, H, T]
+  const float* keep;                              // [B, T] 1 = attend, 0 = masked key (or null)
+  int B, T, H, causal;
+  float scale;
+  // backward only
+  const bf16* dout; long lddo;
+  bf16* dq; bf16* dk; bf16* dv; long lddq, lddk, lddv;
+};
+
+__device__ __forceinline__ int at_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// A-operand fragment of X^T (16 columns d0..d0+15 as MFMA rows) over 8 rows given as two 4-row blocks
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int rowblk0, int rowblk1, int dt, int lane) {
+  const int q = (lane >> 2) & 3, p = lane & 3;
+  const int chunk = 2 * dt + (p >> 1), sub = 8 * (p & 1);
+  const bf16x4 lo = lds_read_tr16(img + at_off(rowblk0 + q, chunk) + sub);
+  const bf16x4 hi = lds_read_tr16(img + at_off(rowblk1 + q, chunk) + sub);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 frag_row(const char* img, int row, int chunk) {
+  return *(const bf16x8*)(img + at_off(row, chunk));
+}
+
+// stage rows [0, rows_total) of a [T][64] head slice into LDS (zero rows >= T)
+__device__ __forceinline__ void stage_head(const bf16* g, long ld, long row0, int T, int rows_total, char* img, int tid) {
+  for (int idx = tid; idx < rows_total * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row < T) val = *(const uint4*)(g + (row0 + row) * ld + c * 8);
+    *(uint4*)(img + at_off(row, c)) = val;
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int NKS = (NKT + 1) / 2, TP = 16 * NKT, TP32 = 32 * NKS;
+  __shared__ __attribute__((aligned(16))) char smem[(TP + TP32) * 128];
+  char* Ks = smem;
+  char* Vs = smem + TP * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int T = a.T;
+  const long row0 = (long)b * T;
+  stage_head(a.k + h * 64, a.ldk, row0, T, TP, Ks, tid);
+  stage_head(a.v + h * 64, a.ldv, row0, T, TP32, Vs, tid);
+  __syncthreads();
+  const int nqt = (T + 15) >> 4;
+  const float NEG = -__builtin_inff();
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qi = 16 * qt + li;
+    const int qrow = qi < T ? qi : T - 1;
+    const bf16* qp = a.q + (row0 + qrow) * a.ldq + h * 64 + 8 * g;
+    const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+    int ktmax = NKT - 1;
+    if (a.causal && qt < ktmax) ktmax = qt;
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (kt <= ktmax) {
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, 16 * kt + li, g), qf0, s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, 16 * kt + li, 4 + g), qf1, s[kt], 0, 0, 0);
+      }
+    }
+    float m = NEG;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * g + r;
+        bool ok = kt <= ktmax && key < T && (!a.causal || key <= qi);
+        if (ok && a.keep) ok = a.keep[row0 + key] != 0.f;
+        const float val = ok ? s[kt][r] * a.scale : NEG;
+        s[kt][r] = val;
+        m = fmaxf(m, val);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float msafe = m == NEG ? 0.f : m;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(s[kt][r] - msafe);
+        s[kt][r] = pv;
+        l += pv;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ss = 0; ss < NKS; ++ss) {
+      if (2 * ss <= ktmax) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pf[j] = (bf16)s[2 * ss][j];
+          pf[4 + j] = (2 * ss + 1 < NKT) ? (bf16)s[(2 * ss + 1 < NKT) ? 2 * ss + 1 : 0][j] : (bf16)0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, o[dt], 0, 0, 0);
+      }
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (qi < T) {
+      bf16* op = a.o + (row0 + qi) * a.ldo + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+        *(bf16x4*)(op + 16 * dt) = ov;
+      }
+      if (g == 0 && a.lse) a.lse[((long)b * a.H + h) * T + qi] = msafe + __logf(l);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
+  constexpr int NKS = (NKT + 1) / 2, TP32 = 32 * NKS;
+  constexpr int DS_LD = 2 * TP32 + 16;                     // padded dS row stride (bytes)
+  __shared__ __attribute__((aligned(16))) char smem[4 * TP32 * 128 + TP32 * DS_LD + 2 * TP32 * 4];
+  char* Qs = smem;
+  char* Ks = Qs + TP32 * 128;
+  char* Vs = Ks + TP32 * 128;
+  char* Os = Vs + TP32 * 128;                              // dO
+  char* dSs = Os + TP32 * 128;                             // [q][key] bf16
+  float* lse_s = (float*)(dSs + TP32 * DS_LD);
+  float* del_s = lse_s + TP32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int T = a.T;
+  const long row0 = (long)b * T;
+  stage_head(a.q + h * 64, a.ldq, row0, T, TP32, Qs, tid);
+  stage_head(a.k + h * 64, a.ldk, row0, T, TP32, Ks, tid);
+  stage_head(a.v + h * 64, a.ldv, row0, T, TP32, Vs, tid);
+  stage_head(a.dout + h * 64, a.lddo, row0, T, TP32, Os, tid);
+  // zero dS (tiles skipped by the causal structure are read as zeros), lse, delta = rowsum(dO * O)
+  for (int i = tid; i < TP32 * DS_LD / 16; i += 256) *(uint4*)(dSs + i * 16) = make_uint4(0, 0, 0, 0);
+  for (int rr = tid >> 2; rr < TP32; rr += 64) {
+    const int part = tid & 3;
+    float acc = 0.f;
+    if (rr < T) {
+      const bf16* op = a.o + (row0 + rr) * a.ldo + h * 64 + part * 16;
+      const bf16* dp = a.dout + (row0 + rr) * a.lddo + h * 64 + part * 16;
+      const bf16x8 o0 = *(const bf16x8*)op, o1 = *(const bf16x8*)(op + 8);
+      const bf16x8 d0 = *(const bf16x8*)dp, d1 = *(const bf16x8*)(dp + 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += (float)o0[j] * (float)d0[j] + (float)o1[j] * (float)d1[j];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) {
+      del_s[rr] = acc;
+      lse_s[rr] = rr < T ? a.lse[((long)b * a.H + h) * T + rr] : 1e30f;
+    }
+  }
+  __syncthreads();
+  const int nkt = (T + 15) >> 4;                           // live key / query tiles
+  const float NEG = -__builtin_inff();
+
+  // ---- phase A: this wave's key tiles; loop over query-tile pairs ----
+  for (int kt = wave; kt < nkt; kt += 4) {
+    f32x4 dvT[4], dkT[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dvT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int key = 16 * kt + li;
+    bool key_ok = key < T;
+    if (key_ok && a.keep) key_ok = a.keep[row0 + key] != 0.f;
+    const bf16x8 kf0 = frag_row(Ks, key, g), kf1 = frag_row(Ks, key, 4 + g);
+    const bf16x8 vf0 = frag_row(Vs, key, g), vf1 = frag_row(Vs, key, 4 + g);
+    for (int ss = 0; ss < NKS; ++ss) {
+      if (a.causal && 2 * ss + 1 < kt) continue;           // both query tiles entirely above the diagonal
+      bf16x8 pf, dsf;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * ss + half;
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int qrow = 16 * qt + li;                     // A-operand row of this lane (row read)
+        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, g), kf0, sv, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, 4 + g), kf1, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, g), vf0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, 4 + g), vf1, dp, 0, 0, 0);
+        const float4 ls = *(const float4*)(lse_s + 16 * qt + 4 * g);
+        const float4 de = *(const float4*)(del_s + 16 * qt + 4 * g);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = 16 * qt + 4 * g + r;
+          const bool ok = key_ok && (!a.causal || key <= qi);
+          const float pv = ok ? __expf(sv[r] * a.scale - lsv[r]) : 0.f;
+          const float dsv = pv * (dp[r] - dev[r]) * a.scale;
+          pf[4 * half + r] = (bf16)pv;
+          dsf[4 * half + r] = (bf16)dsv;
+          *(bf16*)(dSs + qi * DS_LD + key * 2) = (bf16)dsv;
+        }
+      }
+      // contraction over the 32 queries of this pair: k index = (half, g, r) on both operands
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dvT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Os, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, dvT[dt], 0, 0, 0);
+        dkT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), dsf, dkT[dt], 0, 0, 0);
+      }
+    }
+    if (key < T) {
+      bf16* dvp = a.dv + (row0 + key) * a.lddv + h * 64 + 4 * g;
+      bf16* dkp = a.dk + (row0 + key) * a.lddk + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 x = {(bf16)dvT[dt][0], (bf16)dvT[dt][1], (bf16)dvT[dt][2], (bf16)dvT[dt][3]};
+        bf16x4 y = {(bf16)dkT[dt][0], (bf16)dkT[dt][1], (bf16)dkT[dt][2], (bf16)dkT[dt][3]};
+        *(bf16x4*)(dvp + 16 * dt) = x;
+        *(bf16x4*)(dkp + 16 * dt) = y;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; this wave's query tiles ----
+  for (int qt = wave; qt < nkt; qt += 4) {
+    f32x4 dqT[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dqT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int qi = 16 * qt + li;
+    for (int ss = 0; ss < NKS; ++ss) {
+      if (a.causal && 32 * ss > 16 * qt + 15) continue;
+      const bf16x8 dsf = *(const bf16x8*)(dSs + qi * DS_LD + (32 * ss + 8 * g) * 2);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dqT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, 32 * ss + 8 * g, 32 * ss + 8 * g + 4, dt, lane), dsf, dqT[dt], 0, 0, 0);
+    }
+    if (qi < T) {
+      bf16* dqp = a.dq + (row0 + qi) * a.lddq + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 x = {(bf16)dqT[dt][0], (bf16)dqT[dt][1], (bf16)dqT[dt][2], (bf16)dqT[dt][3]};
+        *(bf16x4*)(dqp + 16 * dt) = x;
+      }
+    }
+  }
+}
+
+static bool attn_args_ok(const cclip_attn_desc* d, bool bwd) {
+  if (!d || !d->q || !d->k || !d->v || !d->o) return false;
+  if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->T > 128 || d->head_dim != 64) return false;
+  if ((d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7)) return false;
+  if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->o) & 15) return false;
+  if (bwd) {
+    if (!d->dout || !d->dq || !d->dk || !d->dv || !d->lse) return false;
+    if ((d->lddo & 7) || (d->lddq & 7) || (d->lddk & 7) || (d->lddv & 7)) return false;
+    if (((uintptr_t)d->dout | (uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7) return false;
+  }
+  return true;
+}
+
+static AttnArgs attn_pack(const cclip_attn_desc* d) {
+  AttnArgs a;
+  a.q = (const bf16*)d->q; a.k = (const bf16*)d->k; a.v = (const bf16*)d->v;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv;
+  a.o = (bf16*)d->o; a.ldo = d->ldo; a.lse = d->lse; a.keep = d->key_keep;
+  a.B = d->B; a.T = d->T; a.H = d->H; a.causal = d->causal; a.scale = d->scale;
+  a.dout = (const bf16*)d->dout; a.lddo = d->lddo;
+  a.dq = (bf16*)d->dq; a.dk = (bf16*)d->dk; a.dv = (bf16*)d->dv;
+  a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
+  return a;
+}
+
+extern "C" int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream) {
+  if (!attn_args_ok(d, false)) return CCLIP_ERR_ARG;
+  const AttnArgs a = attn_pack(d);
+  dim3 grid(d->B * d->H), block(256);
+  const int nkt = (d->T + 15) / 16;
+  if (nkt <= 2) hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, block, 0, stream, a);
+  else if (nkt <= 4) hipLaunchKernelGGL((attn_fwd_kernel<4>), grid, block, 0, stream, a);
+  else if (nkt <= 5) hipLaunchKernelGGL((attn_fwd_kernel<5>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<8>), grid, block, 0, stream, a);
+  return cclip_launch_status();
+}
+
+extern "C" int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream) {
+  if (!attn_args_ok(d, true)) return CCLIP_ERR_ARG;
+  const AttnArgs a = attn_pack(d);
+  dim3 grid(d->B * d->H), block(256);
+  const int nkt = (d->T + 15) / 16;
+  if (nkt <= 2) hipLaunchKernelGGL((attn_bwd_kernel<2>), grid, block, 0, stream, a);
+  else if (nkt <= 4) hipLaunchKernelGGL((attn_bwd_kernel<4>), grid, block, 0, stream, a);
+  else if (nkt <= 6) hipLaunchKernelGGL((attn_bwd_kernel<6>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_bwd_kernel<8>), grid, block, 0, stream, a);
+  return cclip_launch_status();
+}

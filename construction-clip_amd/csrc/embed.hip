@@ -1,0 +1,220 @@
+// Token / patch embedding plumbing around the towers (all HBM-bound, 16-byte accesses).
+//
+//   patchify        image fp32 NCHW -> bf16 im2col rows [B*T, 3*P*P]; row b*T+0 (class slot) is zero,
+//                   row b*T+1+p is patch p in (c, ky, kx) order = conv1.weight.view(W, -1) order.
+//                   The k=s=P Conv2d of VisionTransformer (reached from CLIP/train.py:161,
+//                   parse_coco.py:43) then IS the bf16 MFMA GEMM against conv1.weight.
+//   vit_embed_ln    x0 = patch_out + positional (+ class_embedding on slot 0); x = ln_pre(x0)
+//   text_embed      x = token_embedding[text] + positional   (CLIP.encode_text head)
+//   embed_scatter   dtoken_embedding[text[i]] += dx[i]       (fp32 atomics, 256 contiguous B / wave-instr)
+//   colsum          out[c] (+)= sum_r in[r][c]               (bias grads, positional grads)
+#include "cclip_common.h"
+#include "../../include/cclip_hip.h"
+
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B,
+                                                       int R, int P, int G) {
+  const int T = G * G + 1, KP = 3 * P * P, chunks = KP / 8;
+  const long total = (long)B * T * chunks;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int ch = (int)(i % chunks);
+    const long row = i / chunks;
+    const int t = (int)(row % T);
+    const long b = row / T;
+    bf16x8 o;
+    if (t == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+    } else {
+      const int p = t - 1, py = p / G, px = p % G;
+      const int k = ch * 8, c = k / (P * P), rem = k % (P * P), ky = rem / P, kx = rem % P;
+      const float* src = img + (((b * 3 + c) * R) + (py * P + ky)) * (long)R + px * P + kx;
+      const float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
+      o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w;
+      o[4] = (bf16)d.x; o[5] = (bf16)d.y; o[6] = (bf16)d.z; o[7] = (bf16)d.w;
+    }
+    *(bf16x8*)(out + row * KP + ch * 8) = o;
+  }
+}
+
+// one wave per token row: x0 = patch_out[row] + pos[t] (+ cls if t == 0); LayerNorm(x0) -> x
+template <int NV>
+__global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* __restrict__ patch_out,
+                                                           const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, int rows, int T, int D,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ x0, float* __restrict__ x,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_d = 1.0f / (float)D;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const int t = r % T;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int col = c * 256 + lane * 4;
+      v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col < D) {
+        const float4 a = *(const float4*)(patch_out + (long)r * D + col);
+        const float4 p = *(const float4*)(pos + (long)t * D + col);
+        v[c] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        if (t == 0) {
+          const float4 cc = *(const float4*)(cls + col);
+          v[c].x += cc.x; v[c].y += cc.y; v[c].z += cc.z; v[c].w += cc.w;
+        }
+        if (x0) *(float4*)(x0 + (long)r * D + col) = v[c];
+      }
+      s += v[c].x + v[c].y + v[c].z + v[c].w;
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[r] = mean;
+      if (rstd_out) rstd_out[r] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        const float4 g = *(const float4*)(gamma + col), b = *(const float4*)(beta + col);
+        float4 y;
+        y.x = (v[c].x - mean) * rstd * g.x + b.x;
+        y.y = (v[c].y - mean) * rstd * g.y + b.y;
+        y.z = (v[c].z - mean) * rstd * g.z + b.z;
+        y.w = (v[c].w - mean) * rstd * g.w + b.w;
+        *(float4*)(x + (long)r * D + col) = y;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ text, const float* __restrict__ emb,
+                                                         const float* __restrict__ pos, int rows, int L, int D, int V,
+                                                         float* __restrict__ x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    int tok = text[r];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    const int t = r % L;
+    for (int col = lane * 4; col < D; col += 256) {
+      const float4 e = *(const float4*)(emb + (long)tok * D + col);
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pos) p = *(const float4*)(pos + (long)t * D + col);
+      *(float4*)(x + (long)r * D + col) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int* __restrict__ text, const float* __restrict__ dx,
+                                                                long lddx, int rows, int D, int V, float* __restrict__ demb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    int tok = text[r];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    for (int col = lane; col < D; col += 64) atomicAdd(demb + (long)tok * D + col, dx[(long)r * lddx + col]);
+  }
+}
+
+// column sums, two deterministic passes: part[rs][c] then out[c].  4 columns per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ in, long ld, int R, int C,
+                                                             float* __restrict__ part) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + lane * 4;
+  const int rs = blockIdx.y, nrs = gridDim.y;
+  const int r_per = (R + nrs - 1) / nrs;
+  const int r0 = rs * r_per, r1 = (r0 + r_per < R) ? r0 + r_per : R;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < C) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x4 t = *(const bf16x4*)((const bf16*)in + (long)r * ld + col);
+        acc.x += (float)t[0]; acc.y += (float)t[1]; acc.z += (float)t[2]; acc.w += (float)t[3];
+      } else {
+        const float4 t = *(const float4*)((const float*)in + (long)r * ld + col);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+    }
+  }
+  *(float4*)&red[wave][lane * 4] = acc;
+  __syncthreads();
+  if (wave == 0 && col < C) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float4 t = *(const float4*)&red[w][lane * 4];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *(float4*)(part + (long)rs * C + col) = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nrs, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < nrs; ++r) s += part[(long)r * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+static int grid_rows4(int rows) { int g = (rows + 3) / 4; return g > 4096 ? 4096 : (g < 1 ? 1 : g); }
+
+extern "C" int cclip_patchify(const float* image, void* out_bf16, int32_t B, int32_t R, int32_t P, hipStream_t stream) {
+  if (!image || !out_bf16 || B <= 0 || P <= 0 || R % P || (P & 7) || ((uintptr_t)image & 15)) return CCLIP_ERR_ARG;
+  const int G = R / P;
+  const long total = (long)B * (G * G + 1) * (3 * P * P / 8);
+  long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(patchify_kernel, dim3((int)blocks), dim3(256), 0, stream, image, (bf16*)out_bf16, B, R, P, G);
+  return cclip_launch_status();
+}
+
+extern "C" int cclip_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, int32_t rows, int32_t T,
+                                  int32_t D, const float* gamma, const float* beta, float eps, float* x0, float* x,
+                                  float* mean, float* rstd, hipStream_t stream) {
+  if (!patch_out || !cls || !pos || !gamma || !beta || !x || rows <= 0 || T <= 0 || (D & 3) || D > 1024) return CCLIP_ERR_ARG;
+  dim3 grid(grid_rows4(rows)), block(256);
+  const int nv = (D + 255) / 256;
+#define VE(NV) hipLaunchKernelGGL((vit_embed_ln_kernel<NV>), grid, block, 0, stream, patch_out, cls, pos, rows, T, D, gamma, beta, eps, x0, x, mean, rstd)
+  switch (nv) { case 1: VE(1); break; case 2: VE(2); break; case 3: VE(3); break; default: VE(4); }
+#undef VE
+  return cclip_launch_status();
+}
+
+extern "C" int cclip_text_embed(const int32_t* text, const float* emb, const float* pos, int32_t rows, int32_t L,
+                                int32_t D, int32_t V, float* x, hipStream_t stream) {
+  if (!text || !emb || !x || rows <= 0 || L <= 0 || (D & 3) || V <= 0) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(text_embed_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, text, emb, pos, rows, L, D, V, x);
+  return cclip_launch_status();
+}
+
+extern "C" int cclip_embed_scatter_add(const int32_t* text, const float* dx, int64_t lddx, int32_t rows, int32_t D,
+                                       int32_t V, float* demb, hipStream_t stream) {
+  if (!text || !dx || !demb || rows <= 0 || D <= 0 || V <= 0) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, text, dx, (long)lddx, rows, D, V, demb);
+  return cclip_launch_status();
+}
+
+static int colsum_splits(int R) { int s = (R + 127) / 128; return s > 64 ? 64 : (s < 1 ? 1 : s); }
+extern "C" int cclip_colsum_ws_floats(int32_t R, int32_t C) { return colsum_splits(R) * C; }
+extern "C" int cclip_colsum(const void* in, int32_t in_is_bf16, int64_t ld, int32_t R, int32_t C, float* out,
+                            int32_t accumulate, float* ws, hipStream_t stream) {
+  if (!in || !out || !ws || R <= 0 || C <= 0 || (C & 3) || (ld & 3)) return CCLIP_ERR_ARG;
+  const int nrs = colsum_splits(R);
+  dim3 grid((C + 255) / 256, nrs), block(256);
+  if (in_is_bf16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, block, 0, stream, (const bf16*)in, (long)ld, R, C, ws);
+  else hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, stream, (const float*)in, (long)ld, R, C, ws);
+  int st = cclip_launch_status();
+  if (st != CCLIP_OK) return st;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, nrs, C, out, accumulate);
+  return cclip_launch_status();
+}

@@ -1,0 +1,97 @@
+// Exact-fp32 GEMM on the f32-input MFMA (v_mfma_f32_16x16x4_f32: bitwise a k-ordered fmaf chain)
+// for the small, accuracy-critical "head" of the model: pooled-token projections
+// (`x @ visual.proj`, `x @ text_projection`), the cosine-similarity logits
+// `logit_scale.exp() * I @ T.t()` of CLIP.forward (/root/reference/CLIP/train.py:161,
+// /root/reference/CLIP/predict.py:46 - where bit-exact argmax against the CPU oracle is decided)
+// and their backward products.  ~0.05 % of the step's FLOPs, so generic strides beat tuning:
+//
+//   C[m*ldc + n] = alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m*ldc + n]
+//
+// 64x64x16 tile, 4 waves (2x2), each wave 32x32 as 2x2 MFMA tiles; operands staged through LDS
+// (+1-padded rows).  The MFMA is issued swapped (B as the A operand) so each lane ends up with
+// 4 consecutive n of one m -> 16-byte stores.
+#include "cclip_common.h"
+#include "../../include/cclip_hip.h"
+
+#define FBM 64
+#define FBN 64
+#define FBK 16
+#define FLD (FBK + 1)
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
+                                                       const float* __restrict__ B, long sbn, long sbk, int M, int N,
+                                                       int K, float alpha, float beta, float* __restrict__ C, long ldc) {
+  __shared__ float As[FBM * FLD], Bs[FBN * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int bm0 = blockIdx.y * FBM, bn0 = blockIdx.x * FBN;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool a_kfast = sak == 1, b_kfast = sbk == 1;
+  for (int k0 = 0; k0 < K; k0 += FBK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      int m, k;
+      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
+      float v = 0.f;
+      if (bm0 + m < M && k0 + k < K) v = A[(long)(bm0 + m) * sam + (long)(k0 + k) * sak];
+      As[m * FLD + k] = v;
+      int n, kb;
+      if (b_kfast) { n = idx >> 4; kb = idx & 15; } else { kb = idx >> 6; n = idx & 63; }
+      float w = 0.f;
+      if (bn0 + n < N && k0 + kb < K) w = B[(long)(bn0 + n) * sbn + (long)(k0 + kb) * sbk];
+      Bs[n * FLD + kb] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = As[(wm0 + 16 * t + li) * FLD + 4 * kk + g];
+        bf[t] = Bs[(wn0 + 16 * t + li) * FLD + 4 * kk + g];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = 4g + r][j = li]: i <-> n (from the B-side operand), j <-> m
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = bm0 + wm0 + 16 * mt + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n0 = bn0 + wn0 + 16 * nt + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r;
+        if (n < N) {
+          float* cp = C + (long)m * ldc + n;
+          float v = alpha * acc[mt][nt][r];
+          if (beta != 0.f) v += beta * *cp;
+          *cp = v;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                              int32_t M, int32_t N, int32_t K, float alpha, float beta, float* C, int64_t ldc,
+                              hipStream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return CCLIP_ERR_ARG;
+  dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM), block(256);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, stream, A, (long)sam, (long)sak, B, (long)sbn, (long)sbk, M, N, K,
+                     alpha, beta, C, (long)ldc);
+  return cclip_launch_status();
+}

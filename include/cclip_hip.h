@@ -75,6 +75,103 @@ typedef struct cclip_gemm_desc {
 } cclip_gemm_desc;
 int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream);
 
+/* ---- LayerNorm (fp32 statistics, eps as given) ---------------------------------------------
+ * Replaces nn.LayerNorm (ln_pre / ln_1 / ln_2 / ln_post / ln_final; GPT-2 ln_1 / ln_2 / ln_f).
+ * x: fp32 rows of D (row stride ldx); row r of the output normalises input row
+ * (row_index ? row_index[r] : r) - the index form is the pooled `ln_post(x[:,0])` /
+ * `ln_final(x)[n, argmax]`.  Outputs: bf16 and/or fp32 [rows, D] (row stride ldo), optional
+ * mean[rows], rstd[rows] for backward.  D % 4 == 0, D <= 1024. */
+int cclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, int32_t rows, int32_t D,
+                        const float* gamma, const float* beta, float eps, void* out_bf16, float* out_f32,
+                        int64_t ldo, float* mean, float* rstd, hipStream_t stream);
+/* Backward.  dy: [rows, D] bf16 (dy_is_bf16) or fp32.  dx is written at the *input* row
+ * (row_index applied): dx_out[src] = (dx_res ? dx_res[src] : 0) + dLN; optional bf16 copy.
+ * dgamma/dbeta (both or neither): column sums over rows, `accumulate` adds to existing values;
+ * ws must hold cclip_layernorm_bwd_ws_floats(rows, D) floats. */
+int cclip_layernorm_bwd_ws_floats(int32_t rows, int32_t D);
+int cclip_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx,
+                        const int32_t* row_index, int32_t rows, int32_t D, const float* gamma,
+                        const float* mean, const float* rstd, const float* dx_res, float* dx_out,
+                        void* dx_out_bf16, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                        float* ws, hipStream_t stream);
+
+/* ---- fused multi-head attention, head_dim 64, T <= 128 ---------------------------------------
+ * Replaces softmax(q k^T * scale + mask) v of nn.MultiheadAttention (CLIP towers; causal for the
+ * text tower) and of GPT-2 (causal + key padding).  q/k/v/o/d*: bf16, row (b*T + t), head h at
+ * column h*64 of the given base pointer (so a packed [B*T, 3D] qkv buffer is passed as three
+ * offset pointers with the same row stride).  lse: fp32 [B,H,T] written by fwd, read by bwd.
+ * key_keep: optional fp32 [B,T], 0 masks a key.  Backward needs o (for rowsum(dO*O)). */
+typedef struct cclip_attn_desc {
+  const void* q; const void* k; const void* v;
+  int64_t ldq, ldk, ldv;
+  void* o; int64_t ldo;
+  float* lse;
+  const float* key_keep;
+  int32_t B, T, H, head_dim, causal;
+  float scale;
+  const void* dout; int64_t lddo;
+  void* dq; void* dk; void* dv;
+  int64_t lddq, lddk, lddv;
+} cclip_attn_desc;
+int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream);
+int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream);
+
+/* ---- exact fp32 GEMM (f32-input MFMA), generic strides ---------------------------------------
+ * C[m*ldc+n] = alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m*ldc+n].
+ * Replaces `x @ visual.proj`, `x @ text_projection`, `logit_scale.exp() * I @ T.t()` of
+ * CLIP.forward/encode_* and their backward products (tiny, accuracy critical). */
+int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                   int32_t M, int32_t N, int32_t K, float alpha, float beta, float* C, int64_t ldc,
+                   hipStream_t stream);
+
+/* ---- embeddings ------------------------------------------------------------------------------
+ * cclip_patchify: image fp32 [B,3,R,R] -> bf16 im2col [B*T, 3*P*P], T = (R/P)^2 + 1, class slot
+ *   row (t = 0) zero; column order (c, ky, kx) = conv1.weight.view(W,-1).  P % 8 == 0.
+ *   Replaces the input side of VisionTransformer.conv1 (k = s = P, no bias).
+ * cclip_vit_embed_ln: x0 = patch_out + positional_embedding[t] (+ class_embedding at t = 0),
+ *   x = ln_pre(x0); optional saves x0, mean, rstd.  All fp32 [rows = B*T, D].
+ * cclip_text_embed: x[r] = token_embedding[text[r]] + positional_embedding[r % L] (pos may be NULL).
+ * cclip_embed_scatter_add: demb[text[r]] += dx[r]   (fp32 atomics).
+ * cclip_colsum: out[c] (+)= sum_r in[r*ld + c]; in bf16 or fp32; C % 4 == 0; deterministic;
+ *   ws >= cclip_colsum_ws_floats(R, C) floats. */
+int cclip_patchify(const float* image, void* out_bf16, int32_t B, int32_t R, int32_t P, hipStream_t stream);
+int cclip_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, int32_t rows, int32_t T,
+                       int32_t D, const float* gamma, const float* beta, float eps, float* x0, float* x,
+                       float* mean, float* rstd, hipStream_t stream);
+int cclip_text_embed(const int32_t* text, const float* emb, const float* pos, int32_t rows, int32_t L,
+                     int32_t D, int32_t V, float* x, hipStream_t stream);
+int cclip_embed_scatter_add(const int32_t* text, const float* dx, int64_t lddx, int32_t rows, int32_t D,
+                            int32_t V, float* demb, hipStream_t stream);
+int cclip_colsum_ws_floats(int32_t R, int32_t C);
+int cclip_colsum(const void* in, int32_t in_is_bf16, int64_t ld, int32_t R, int32_t C, float* out,
+                 int32_t accumulate, float* ws, hipStream_t stream);
+
+/* ---- loss side (fp32) ------------------------------------------------------------------------
+ * cclip_l2norm_fwd/bwd: y = x / ||x||_2 per row (image_features / image_features.norm(dim=1)).
+ * cclip_xent_rows: per row r with label labels[r]: loss_row = logsumexp(row) - row[label]
+ *   (0 when label == ignore_index), pred = argmax(row) (first max), and, if dlogits != NULL,
+ *   dlogits = (softmax(row) - onehot) * grad_scale (fp32, may alias logits; or bf16, must not).
+ *   Replaces torch.nn.CrossEntropyLoss + torch.argmax of CLIP/train.py:162-173 and
+ *   nnf.cross_entropy(ignore_index=0) of CLIP_prefix_caption/train.py:357. */
+int cclip_l2norm_fwd(const float* x, int64_t ldx, int32_t rows, int32_t D, float* y, int64_t ldy,
+                     float* inv_norm, hipStream_t stream);
+int cclip_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* inv_norm,
+                     int32_t rows, int32_t D, float* dx, int64_t lddx, hipStream_t stream);
+int cclip_xent_rows(const float* logits, int64_t ld, int32_t R, int32_t C, const int32_t* labels,
+                    int32_t ignore_index, float grad_scale, float* loss_row, int32_t* pred,
+                    void* dlogits, int32_t dlogits_is_bf16, int64_t ldd, hipStream_t stream);
+
+/* ---- optimiser over the flat parameter arena -------------------------------------------------
+ * mode 0: transformers.AdamW (CLIP/train.py:143): p -= lr*sqrt(bc2)/bc1 * m/(sqrt(v)+eps), then
+ * p -= lr*wd*p.  mode 1: torch.optim.AdamW.  grad is multiplied by grad_scale first.  If
+ * bf16_shadow != NULL the bf16 compute copy of the weights is rewritten in the same pass.
+ * n % 4 == 0, buffers 16-byte aligned, step >= 1. */
+int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                     int32_t correct_bias, float grad_scale, int32_t mode, void* bf16_shadow,
+                     hipStream_t stream);
+int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

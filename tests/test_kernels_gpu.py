@@ -1,0 +1,261 @@
+"""GPU parity of every non-GEMM HIP kernel against a plain torch fp32 reference of the same op
+(the model-level comparison against the CPU oracle lives in test_clip_parity_gpu.py).
+Tolerances are written per test: fp32 kernels 1e-5..1e-4 relative; kernels with bf16 I/O are
+limited by one bf16 rounding (2^-8) of their inputs/outputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ops():
+    from cclip_hip import ops as o
+    return o
+
+
+def close(name, got, ref, rtol, atol=0.0):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs().max().clamp_min(1e-12)
+    if not bool((err <= bound).all()) or not bool(torch.isfinite(got).all()):
+        bad = (err > bound) | ~torch.isfinite(got)
+        idx = bad.nonzero()[:6].tolist()
+        pytest.fail(f"{name}: {int(bad.sum())}/{bad.numel()} bad; max err {err[torch.isfinite(err)].max().item() if torch.isfinite(err).any() else float('nan'):.4g} "
+                    f"bound {bound.item():.4g}; first {idx}; got {[got[tuple(i)].item() for i in idx[:3]]} ref {[ref[tuple(i)].item() for i in idx[:3]]}")
+
+
+def G(seed):
+    return torch.Generator(device="cuda").manual_seed(seed)
+
+
+@pytest.mark.parametrize("rows,D", [(7, 128), (1000, 512), (513, 768), (64, 1024)])
+def test_layernorm_fwd_bwd(rows, D):
+    o = ops()
+    g = G(rows + D)
+    x = torch.randn(rows, D, device="cuda", generator=g) * 2 + 0.5
+    gamma = 1 + 0.1 * torch.randn(D, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(D, device="cuda", generator=g)
+    dy = torch.randn(rows, D, device="cuda", generator=g)
+    res = torch.randn(rows, D, device="cuda", generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    y.backward(dy)
+    out_b = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    out_f = torch.empty(rows, D, device="cuda")
+    mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    o.layernorm_fwd(x, gamma, beta, rows=rows, out_bf16=out_b, out_f32=out_f, mean=mean, rstd=rstd)
+    close("ln f32", out_f, y, 1e-5, 1e-5)
+    close("ln bf16", out_b, y, 2 ** -7)
+    close("mean", mean, x.mean(1), 1e-5, 1e-6)
+    dx = torch.empty(rows, D, device="cuda"); dxb = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    dg = torch.ones(D, device="cuda"); db = torch.ones(D, device="cuda")
+    ws = torch.empty(o.layernorm_bwd_ws_floats(rows, D), device="cuda")
+    o.layernorm_bwd(dy, x, gamma, mean, rstd, rows=rows, dx_res=res, dx_out=dx, dx_out_bf16=dxb, dgamma=dg, dbeta=db,
+                    accumulate=True, ws=ws)
+    close("ln dx", dx, xr.grad + res, 1e-4, 1e-5)
+    close("ln dx bf16", dxb, xr.grad + res, 2 ** -7)
+    close("ln dgamma", dg, gr.grad + 1, 1e-4, 1e-4)
+    close("ln dbeta", db, br.grad + 1, 1e-4, 1e-4)
+    # bf16 upstream gradient, no accumulate
+    o.layernorm_bwd(dy.bfloat16(), x, gamma, mean, rstd, rows=rows, dx_out=dx, dgamma=dg, dbeta=db, ws=ws)
+    xr.grad = None; gr.grad = None
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5).backward(dy.bfloat16().float())
+    close("ln dx (bf16 dy)", dx, xr.grad, 1e-4, 1e-5)
+    close("ln dgamma (bf16 dy)", dg, gr.grad, 1e-4, 1e-4)
+
+
+def test_layernorm_row_index():
+    o = ops()
+    g = G(3)
+    x = torch.randn(40, 256, device="cuda", generator=g)
+    idx = torch.tensor([0, 10, 39, 5], device="cuda", dtype=torch.int32)
+    gamma = torch.rand(256, device="cuda", generator=g) + 0.5
+    beta = torch.randn(256, device="cuda", generator=g)
+    out = torch.empty(4, 256, device="cuda")
+    mean = torch.empty(4, device="cuda"); rstd = torch.empty(4, device="cuda")
+    o.layernorm_fwd(x, gamma, beta, rows=4, row_index=idx, out_f32=out, mean=mean, rstd=rstd)
+    ref = torch.nn.functional.layer_norm(x[idx.long()], (256,), gamma, beta, 1e-5)
+    close("ln gather", out, ref, 1e-5, 1e-5)
+    dy = torch.randn(4, 256, device="cuda", generator=g)
+    dx = torch.zeros(40, 256, device="cuda")
+    o.layernorm_bwd(dy, x, gamma, mean, rstd, rows=4, row_index=idx, dx_out=dx)
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr[idx.long()], (256,), gamma, beta, 1e-5).backward(dy)
+    close("ln scatter dx", dx, xr.grad, 1e-4, 1e-5)
+
+
+def _attn_ref(q, k, v, causal, keep):
+    # q,k,v: [B,H,T,64] fp32
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    T = q.shape[2]
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), device=q.device).triu_(1)
+    if keep is not None:
+        s = s.masked_fill(keep[:, None, None, :] == 0, float("-inf"))
+    return torch.softmax(s, dim=-1) @ v
+
+
+@pytest.mark.parametrize("B,T,H,causal,pad", [(3, 50, 12, False, False), (2, 77, 8, True, False), (2, 5, 2, False, False),
+                                              (3, 80, 12, True, True), (1, 128, 3, True, False), (2, 33, 2, False, True),
+                                              (2, 17, 1, True, False), (1, 100, 2, False, False)])
+def test_attention_fwd_bwd(B, T, H, causal, pad):
+    o = ops()
+    g = G(B * 1000 + T)
+    D = H * 64
+    qkv = torch.randn(B * T, 3 * D, device="cuda", generator=g).bfloat16()
+    keep = None
+    if pad:
+        keep = torch.ones(B, T, device="cuda")
+        keep[0, T - 3:] = 0
+        keep[-1, T // 2:] = 0
+    out = torch.full((B * T, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, T, device="cuda")
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    o.attention_fwd(q, k, v, out, B=B, T=T, H=H, causal=causal, key_keep=keep, lse=lse)
+    f = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    ref = _attn_ref(f[0], f[1], f[2], causal, keep)            # [B,H,T,64]
+    ref2 = ref.permute(0, 2, 1, 3).reshape(B * T, D)
+    close("attn fwd", out, ref2, 1.5e-2)
+    dout = torch.randn(B * T, D, device="cuda", generator=g).bfloat16()
+    dqkv = torch.full((B * T, 3 * D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    o.attention_bwd(q, k, v, out, lse, dout, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B=B, T=T, H=H, causal=causal,
+                    key_keep=keep)
+    ref.backward(dout.float().view(B, T, H, 64).permute(0, 2, 1, 3))
+    gref = f.grad.permute(1, 3, 0, 2, 4).reshape(B * T, 3 * D)
+    close("attn dq", dqkv[:, :D], gref[:, :D], 3e-2)
+    close("attn dk", dqkv[:, D:2 * D], gref[:, D:2 * D], 3e-2)
+    close("attn dv", dqkv[:, 2 * D:], gref[:, 2 * D:], 3e-2)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(9, 9, 512, False, False), (1024, 1024, 512, False, False), (100, 70, 33, True, False),
+                                         (65, 130, 768, False, True), (512, 768, 100, True, True)])
+def test_gemm_f32(M, N, K, ta, tb):
+    o = ops()
+    g = G(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), device="cuda", generator=g)
+    B = torch.randn((K, N) if tb else (N, K), device="cuda", generator=g)
+    Av = A.t() if ta else A
+    Bv = B.t() if tb else B
+    C = torch.randn(M, N, device="cuda", generator=g)
+    ref = 0.5 * (Av.double() @ Bv.double().t()) + 2.0 * C.double()
+    o.gemm_f32(Av, Bv, C, alpha=0.5, beta=2.0)
+    close("gemm_f32", C, ref.float(), 2e-6 * math.sqrt(K) + 1e-6)
+
+
+def test_patchify_and_embeds():
+    o = ops()
+    g = G(11)
+    B, R, P, W = 3, 64, 32, 128
+    Gd = R // P
+    T = Gd * Gd + 1
+    img = torch.randn(B, 3, R, R, device="cuda", generator=g)
+    out = torch.full((B * T, 3 * P * P), float("nan"), device="cuda", dtype=torch.bfloat16)
+    o.patchify(img, out, P)
+    ref = torch.nn.functional.unfold(img, kernel_size=P, stride=P).transpose(1, 2)      # [B, G*G, 3*P*P]
+    ref = torch.cat([torch.zeros(B, 1, 3 * P * P, device="cuda"), ref], 1).reshape(B * T, -1)
+    close("patchify", out, ref.bfloat16().float(), 0.0, 0.0)
+    po = torch.randn(B * T, W, device="cuda", generator=g)
+    cls = torch.randn(W, device="cuda", generator=g); pos = torch.randn(T, W, device="cuda", generator=g)
+    gamma = torch.rand(W, device="cuda", generator=g) + 0.5; beta = torch.randn(W, device="cuda", generator=g)
+    x = torch.empty(B * T, W, device="cuda"); x0 = torch.empty(B * T, W, device="cuda")
+    mean = torch.empty(B * T, device="cuda"); rstd = torch.empty(B * T, device="cuda")
+    o.vit_embed_ln(po, cls, pos, gamma, beta, x, rows=B * T, T=T, x0=x0, mean=mean, rstd=rstd)
+    r0 = po.view(B, T, W) + pos
+    r0[:, 0] += cls
+    close("x0", x0, r0.reshape(B * T, W), 1e-6, 1e-6)
+    close("ln_pre", x, torch.nn.functional.layer_norm(r0, (W,), gamma, beta, 1e-5).reshape(B * T, W), 1e-5, 1e-5)
+    # text embed + scatter
+    V, L = 300, 16
+    text = torch.randint(0, V, (B * L,), device="cuda", generator=g, dtype=torch.int32)
+    emb = torch.randn(V, W, device="cuda", generator=g); posl = torch.randn(L, W, device="cuda", generator=g)
+    xt = torch.empty(B * L, W, device="cuda")
+    o.text_embed(text, emb, posl, xt, rows=B * L, L=L)
+    close("text_embed", xt, (emb[text.long()].view(B, L, W) + posl).reshape(B * L, W), 1e-6, 1e-6)
+    dx = torch.randn(B * L, W, device="cuda", generator=g)
+    demb = torch.zeros(V, W, device="cuda")
+    o.embed_scatter_add(text, dx, demb, rows=B * L)
+    ref = torch.zeros(V, W, device="cuda").index_add_(0, text.long(), dx)
+    close("scatter", demb, ref, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("R,C,bf", [(1000, 768, True), (50, 2304, False), (4097, 100, True)])
+def test_colsum(R, C, bf):
+    o = ops()
+    g = G(R)
+    x = torch.randn(R, C, device="cuda", generator=g)
+    if bf:
+        x = x.bfloat16()
+    out = torch.ones(C, device="cuda")
+    ws = torch.empty(o.colsum_ws_floats(R, C), device="cuda")
+    o.colsum(x, out, ws, R=R, C=C, ld=C, accumulate=True)
+    close("colsum", out, 1 + x.float().sum(0), 1e-5, 1e-4)
+
+
+def test_l2norm_and_xent():
+    o = ops()
+    g = G(21)
+    x = torch.randn(37, 512, device="cuda", generator=g)
+    y = torch.empty_like(x); inv = torch.empty(37, device="cuda")
+    o.l2norm_fwd(x, y, inv)
+    xr = x.clone().requires_grad_(True)
+    yr = xr / xr.norm(dim=1, keepdim=True)
+    close("l2norm", y, yr, 1e-6, 1e-7)
+    dy = torch.randn_like(x)
+    yr.backward(dy)
+    dx = torch.empty_like(x)
+    o.l2norm_bwd(dy, y, inv, dx)
+    close("l2norm bwd", dx, xr.grad, 1e-5, 1e-7)
+    for R, C in [(9, 9), (1, 2), (300, 1000), (64, 21128)]:
+        lg = torch.randn(R, C, device="cuda", generator=g) * 3
+        labels = torch.randint(0, C, (R,), device="cuda", generator=g, dtype=torch.int32)
+        if R > 8:
+            labels[3] = 0
+        lr = lg.clone().requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(lr, labels.long(), ignore_index=0, reduction="sum")
+        loss.backward()
+        lrow = torch.empty(R, device="cuda"); pred = torch.empty(R, device="cuda", dtype=torch.int32)
+        d = torch.empty_like(lg); db = torch.empty(R, C, device="cuda", dtype=torch.bfloat16)
+        o.xent_rows(lg, labels, loss_row=lrow, pred=pred, dlogits=d, grad_scale=0.5, ignore_index=0)
+        o.xent_rows(lg, labels, dlogits=db, grad_scale=0.5, ignore_index=0)
+        close(f"xent loss {R}x{C}", lrow.sum(), loss.detach(), 1e-5, 1e-5)
+        close(f"xent grad {R}x{C}", d, 0.5 * lr.grad, 1e-5, 1e-7)
+        close(f"xent grad bf16 {R}x{C}", db, 0.5 * lr.grad, 2 ** -7, 1e-7)
+        assert torch.equal(pred.long(), lg.argmax(1)), "argmax mismatch"
+        lg2 = lg.clone()
+        o.xent_rows(lg2, labels, dlogits=lg2, grad_scale=0.5, ignore_index=0)   # in place
+        close("xent inplace", lg2, d, 0.0, 0.0)
+
+
+def test_adamw_matches_hf_form():
+    o = ops()
+    g = G(5)
+    n = 4096 + 64
+    p = torch.randn(n, device="cuda", generator=g); gr = torch.randn(n, device="cuda", generator=g)
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    pr, mr, vr = p.clone().double(), m.clone().double(), v.clone().double()
+    sh = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-6, 0.01
+    for step in range(1, 4):
+        o.adamw_step(p, gr, m, v, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=step, bf16_shadow=sh)
+        mr = b1 * mr + (1 - b1) * gr.double()
+        vr = b2 * vr + (1 - b2) * gr.double() ** 2
+        ss = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        pr = pr - ss * mr / (vr.sqrt() + eps)
+        pr = pr - lr * wd * pr
+    close("adamw p", p, pr.float(), 1e-5, 1e-6)
+    close("adamw shadow", sh, pr.float(), 2 ** -8)
+    # torch.optim.AdamW form
+    p2 = torch.randn(n, device="cuda", generator=g)
+    tp = torch.nn.Parameter(p2.clone()); tp.grad = gr.clone()
+    opt = torch.optim.AdamW([tp], lr=lr, betas=(b1, b2), eps=1e-8, weight_decay=wd)
+    m.zero_(); v.zero_()
+    for step in range(1, 3):
+        opt.step()
+        o.adamw_step(p2, gr, m, v, lr=lr, beta1=b1, beta2=b2, eps=1e-8, weight_decay=wd, step=step, mode=1)
+    close("adamw torch form", p2, tp.detach(), 1e-5, 1e-6)
+    src = torch.randn(1024, device="cuda", generator=g); dst = torch.empty(1024, device="cuda", dtype=torch.bfloat16)
+    o.cast_f32_to_bf16(src, dst)
+    assert torch.equal(dst, src.bfloat16())
