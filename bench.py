@@ -1,0 +1,213 @@
+"""Headline benchmark: image-text pairs/sec of the CLIP ViT-B/32 contrastive step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode train|fwd] [--batch 1024]
+
+Workload (BASELINE.json configs[1]): CLIP/train.py's step `model(image, text)` -> symmetric CE ->
+backward -> AdamW, scaled to bs = 1024 pairs per GPU, synthetic 224x224 N(0,1) images + 77-token captions
+(SURVEY.md 8d), seeded OpenAI-style weights, bf16 MFMA operands / fp32 accumulate / fp32 masters.
+One "step" = encode_image + encode_text + logits + loss + full backward + optimiser step over one batch.
+`--mode fwd` times encode + logits only (reported as an extra, never as `value` by default).
+N > 1: one process per GPU (torchrun contract), weak scaling (per-GPU batch fixed), embedding
+all-gather + reduce-scatter and SUM all-reduce of the flat gradient arena over RCCL.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     - dominant kernel family gemm_bf16_128<*> (97 % of the step's FLOPs): algorithmic FLOPs of
+                 every launch in the timed region (2*M*N*K) / their summed durations (HIP events on the launch
+                 stream), against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline - the CPU oracle (kind "port": the reference's `clip` package is absent) timed
+                 on the host cores for the same step on a bounded batch.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "construction-clip_amd")]
+
+PAIR_FWD_FLOPS = 14_777_163_776          # encode_image 8 817 623 040 + encode_text 5 959 540 736
+PEAK_BF16 = 2.5e15                       # dense bf16 MFMA, MI355X_MICROARCH.md
+
+
+def cpu_baseline(mode: str, budget_s: float = 20.0):
+    """Oracle step on the host cores: bounded sample (batch 16), median of a few iterations."""
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    from oracle import clip_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    geo = MODELS["ViT-B/32"]
+    bs = 16
+    sd = init_state_dict(geo, 567)
+    img, txt = synthetic_images(bs, geo, 568), synthetic_text(bs, geo, 569)
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        if mode == "train":
+            sdg = {k: v.requires_grad_(True) for k, v in sd.items()}
+            li, lt = O.clip_forward(sdg, img, txt)
+            loss, _ = O.contrastive_loss(li, lt)
+            loss.backward()
+            for v in sdg.values():
+                v.grad = None
+        else:
+            with torch.no_grad():
+                O.clip_forward(sd, img, txt)
+        times.append(time.time() - t0)
+        log(f"cpu baseline iteration {it}: {times[-1]:.2f}s")
+        if time.time() - t_all > budget_s and it >= 1:
+            break
+    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return dict(value=bs / t, unit="pairs/s", cores=cores, kind="port",
+                sample=f"oracle/clip_oracle.py fp32 {mode} step (fwd{'+bwd' if mode == 'train' else ''}), batch {bs}, "
+                       f"median of {len(times) - 1 or 1} iterations after 1 warm-up, torch CPU {cores} threads")
+
+
+def log(msg: str):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)   # where are we, if something stalls
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
+    ap.add_argument("--mode", choices=["train", "fwd"], default="train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="ViT-B/32")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import clip
+    from clip import optim as coptim
+    from clip import parallel
+    from clip.weights import MODELS, init_state_dict, synthetic_text
+    from cclip_hip import ops
+
+    rank, world, local = parallel.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    geo = MODELS[args.model]
+    B = args.batch
+
+    model = clip.build_model(init_state_dict(geo, 567)).to(dev)
+    model.train()
+    parallel.broadcast_parameters(model)
+    opt = coptim.AdamW(model, lr=1e-5)                       # CLIP/train.py:143 (HF AdamW, lr 1e-5)
+    sched = coptim.get_linear_schedule_with_warmup(opt, 5000, 1000 * 50)   # CLIP/train.py:145-147
+    g = torch.Generator(device=dev).manual_seed(567 + rank)
+    image = torch.randn(B, 3, geo.image_resolution, geo.image_resolution, device=dev, generator=g)
+    text = synthetic_text(B, geo, 567 + rank).to(dev)
+    group = None
+
+    def step():
+        if args.mode == "fwd":
+            with torch.no_grad():
+                fi, ft = model.encode_image(image), model.encode_text(text)
+                loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale, group)
+            return stats
+        opt.zero_grad()
+        fi, ft = model.encode_image(image), model.encode_text(text)
+        loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale, group)
+        loss.backward()
+        parallel.allreduce_gradients(model, group)
+        opt.step()
+        sched.step()
+        return stats
+
+    log(f"model ready on {dev}; warmup x{args.warmup}")
+    for i in range(args.warmup):
+        stats = step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    loss_val = float(stats[0].item())
+    log(f"timed {args.steps} steps in {dt:.3f}s")
+
+    # ---- roofline leg: same steps again with every GEMM launch bracketed by HIP events ----
+    roof = None
+    if rank == 0:
+        ops.GEMM_EVENTS = []
+        nprof = min(2, args.steps)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        ev = ops.GEMM_EVENTS
+        ops.GEMM_EVENTS = None
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)
+        tot_fl = sum(f for _, _, f, *_ in ev)
+        by = {}
+        for e0, e1, f, lay, _shape in ev:
+            k = {(1, 1): "fwd", (1, 0): "dgrad", (0, 0): "wgrad"}[lay]
+            t, fl, n = by.get(k, (0.0, 0.0, 0))
+            by[k] = (t + e0.elapsed_time(e1), fl + f, n + 1)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="gemm_bf16_128<*> (all layouts)", achieved=round(ach, 1),
+                    peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(ach * 1e12 / PEAK_BF16, 4), traffic=None,
+                    launches_per_step=len(ev) // nprof, gemm_ms_per_step=round(tot_ms / nprof, 3),
+                    by_layout={k: dict(tflops=round(fl / (t * 1e-3) / 1e12, 1), ms_per_step=round(t / nprof, 3), launches=n // nprof)
+                               for k, (t, fl, n) in by.items()})
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        value = pairs / dt
+        step_flops = PAIR_FWD_FLOPS * (3 if args.mode == "train" else 1) * B
+        out = {
+            "metric": "image-text pairs/sec (encode+logits) ViT-B/32 bs=1024 at 1/2/4/8 MI355X",
+            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("CLIP/train.py contrastive fine-tune step (fwd+bwd+AdamW)" if args.mode == "train"
+                                    else "encode_image+encode_text+logits forward only") + f", {args.model}, bs={B}/GPU, "
+                       "224x224 N(0,1) images + 77-token captions, seeded synthetic weights",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "mode": args.mode},
+            "step_mfu_bf16": round(step_flops * world / (dt / args.steps) / (PEAK_BF16 * world), 4),
+            "loss": round(loss_val, 5),
+            "roofline": roof,
+        }
+        log("roofline leg done")
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.mode)
+            log("cpu baseline done")
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

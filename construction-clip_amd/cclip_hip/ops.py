@@ -18,6 +18,12 @@ ACT_NONE, ACT_QUICKGELU, ACT_TANH, ACT_GELU_NEW, ACT_RELU = 0, 1, 2, 3, 4
 ACT_DQUICKGELU, ACT_DTANH, ACT_DGELU_NEW, ACT_DRELU = 16, 17, 18, 19
 
 
+# Optional per-launch timing of the dominant kernel family (bench.py's roofline leg): when GEMM_EVENTS is a
+# list, every cclip_gemm_bf16 launch is bracketed by HIP events on the launch stream and
+# (start, end, flops, layout) is appended.  None (default) = zero overhead.
+GEMM_EVENTS = None
+
+
 def _stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -93,6 +99,13 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
         _req(out_f32, torch.float32, "out_f32")
     if split_k > 1:
         assert split_ws is not None and split_ws.numel() >= split_k * M * N and split_ws.dtype == torch.float32
+    if GEMM_EVENTS is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.cclip_gemm_bf16(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
+        e1.record()
+        GEMM_EVENTS.append((e0, e1, 2.0 * M * N * K, (int(a_kcontig), int(b_kcontig)), (M, N, K)))
+        return
     check(lib.cclip_gemm_bf16(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
 
 
@@ -179,14 +192,15 @@ def attention_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H: int, 
 # --------------------------------------------------------------------------------------------
 # exact fp32 GEMM:  C = alpha * A @ B^T-like contraction with arbitrary strides
 # --------------------------------------------------------------------------------------------
-def gemm_f32(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0) -> None:
+def gemm_f32(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
+             alpha_log_dev: Optional[torch.Tensor] = None) -> None:
     """C[m,n] = alpha * sum_k A[m,k] * B[n,k] + beta*C.  A: [M,K], B: [N,K] as (possibly transposed) 2-D views."""
     _req(A, torch.float32, "A"); _req(B, torch.float32, "B"); _req(C, torch.float32, "C")
     M, K = A.shape
     N, Kb = B.shape
     assert K == Kb and C.shape == (M, N) and C.stride(1) == 1
     check(lib.cclip_gemm_f32(_p(A), c_long(A.stride(0)), c_long(A.stride(1)), _p(B), c_long(B.stride(0)),
-                             c_long(B.stride(1)), c_int(M), c_int(N), c_int(K), c_float(alpha), c_float(beta), _p(C),
+                             c_long(B.stride(1)), c_int(M), c_int(N), c_int(K), c_float(alpha), _p(alpha_log_dev), c_float(beta), _p(C),
                              c_long(C.stride(0)), _stream()), "cclip_gemm_f32")
 
 
@@ -234,19 +248,24 @@ def l2norm_fwd(x, y, inv_norm) -> None:
                                _p(inv_norm), _stream()), "cclip_l2norm_fwd")
 
 
-def l2norm_bwd(dy, y, inv_norm, dx) -> None:
+def l2norm_bwd(dy, y, inv_norm, dx, mul_dev=None) -> None:
     check(lib.cclip_l2norm_bwd(_p(dy), c_long(dy.stride(0)), _p(y), c_long(y.stride(0)), _p(inv_norm), c_int(y.shape[0]),
-                               c_int(y.shape[1]), _p(dx), c_long(dx.stride(0)), _stream()), "cclip_l2norm_bwd")
+                               c_int(y.shape[1]), _p(dx), c_long(dx.stride(0)), _p(mul_dev), _stream()), "cclip_l2norm_bwd")
 
 
 def xent_rows(logits, labels_i32, *, loss_row=None, pred=None, dlogits=None, grad_scale: float = 1.0,
-              ignore_index: int = -100) -> None:
+              ignore_index: int = -100, rowdot=None) -> None:
     _req(logits, torch.float32, "logits"); _req(labels_i32, torch.int32, "labels")
     R, C = logits.shape
     check(lib.cclip_xent_rows(_p(logits), c_long(logits.stride(0)), c_int(R), c_int(C), _p(labels_i32), c_int(ignore_index),
                               c_float(grad_scale), _p(loss_row), _p(pred), _p(dlogits),
                               c_int(int(dlogits is not None and dlogits.dtype == torch.bfloat16)),
-                              c_long(0 if dlogits is None else dlogits.stride(0)), _stream()), "cclip_xent_rows")
+                              c_long(0 if dlogits is None else dlogits.stride(0)), _p(rowdot), _stream()), "cclip_xent_rows")
+
+
+def reduce_dot(a, b, out, *, alpha: float = 1.0, mul_dev=None, accumulate: bool = False) -> None:
+    check(lib.cclip_reduce_dot(_p(a), _p(b), c_long(a.numel()), c_float(alpha), _p(mul_dev), _p(out),
+                               c_int(int(accumulate)), _stream()), "cclip_reduce_dot")
 
 
 # --------------------------------------------------------------------------------------------

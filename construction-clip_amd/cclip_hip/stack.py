@@ -1,0 +1,205 @@
+"""Pre-LN transformer block stack executed as an explicit sequence of HIP launches, with a
+hand-written backward (no per-op autograd).  Shared by the CLIP image tower, the CLIP text tower
+and GPT-2: they differ only in weight layout (nn.Linear [out,in] vs Conv1D [in,out]), activation
+(QuickGELU vs gelu_new) and attention mask.
+
+Forward of one block (the `clip` package's ResidualAttentionBlock, reached from
+/root/reference/CLIP/train.py:161; HF GPT2Block behind /root/reference/CLIP_prefix_caption/train.py:268):
+    xn1 = LN1(x)              -> bf16          [layernorm.hip]
+    qkv = xn1 Wqkv^T + b      -> bf16          [gemm_bf16.hip, bias epilogue]
+    a   = softmax(q k^T) v    -> bf16, lse     [attention.hip]
+    x'  = x + a Wo^T + b      -> fp32          [gemm_bf16.hip, bias + residual epilogue]
+    xn2 = LN2(x')             -> bf16
+    g   = act(xn2 Wfc^T + b)  -> bf16 (+ pre-activation h saved for backward, same launch)
+    x'' = x' + g Wproj^T + b  -> fp32
+The residual stream stays fp32; GEMM operands are bf16 with fp32 MFMA accumulation.
+Everything backward needs is kept resident in HBM (~27 KB per token per layer for ViT-B/32):
+288 GB makes recomputation pointless.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class BlockWeights:
+    """bf16 compute copies of the matrices + fp32 vectors of one block, and where their grads go."""
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor
+    w_qkv: torch.Tensor; b_qkv: torch.Tensor
+    w_o: torch.Tensor; b_o: torch.Tensor
+    ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    w_fc: torch.Tensor; b_fc: torch.Tensor
+    w_proj: torch.Tensor; b_proj: torch.Tensor
+    grads: Optional[Dict[str, torch.Tensor]] = None    # same field names -> fp32 grad views (None = frozen)
+
+
+@dataclass
+class StackGeometry:
+    width: int
+    heads: int
+    tokens: int            # sequence length T
+    linear_layout: bool    # True: weights [out, in] (nn.Linear); False: [in, out] (GPT-2 Conv1D)
+    act: int               # ops.ACT_QUICKGELU / ops.ACT_GELU_NEW
+    causal: bool
+
+
+_DACT = {ops.ACT_QUICKGELU: ops.ACT_DQUICKGELU, ops.ACT_GELU_NEW: ops.ACT_DGELU_NEW, ops.ACT_RELU: ops.ACT_DRELU}
+
+
+def wgrad_splits(n_out: int, k_in: int, tokens: int) -> int:
+    """Split the token contraction so that (output tiles x splits) fills the 256 CUs a few times over."""
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    nkt = (tokens + 63) // 64
+    s = max(1, min(32, round(768 / max(tiles, 1))))
+    return max(1, min(s, nkt // 4 if nkt >= 8 else 1))
+
+
+class Scratch:
+    """Grow-only device scratch shared by the launches of one stream (split-K slabs, LN/colsum partials)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._buf: Optional[torch.Tensor] = None
+
+    def floats(self, n: int) -> torch.Tensor:
+        if self._buf is None or self._buf.numel() < n:
+            self._buf = torch.empty(max(n, 1 << 20), device=self.device, dtype=torch.float32)
+        return self._buf
+
+
+class BlockStack:
+    def __init__(self, geo: StackGeometry, blocks: List[BlockWeights], scratch: Scratch):
+        self.geo, self.blocks, self.scratch = geo, blocks, scratch
+
+    # ------------------------------------------------------------------ forward
+    def alloc_saved(self, B: int, device) -> dict:
+        """Activation store for one training forward.  The caller writes the stack input (fp32 [B*T, D])
+        into saved["xs"][0, 0] and passes that view as `x`."""
+        D, T, H = self.geo.width, self.geo.tokens, self.geo.heads
+        M, L = B * T, len(self.blocks)
+        return dict(
+            bf=torch.empty(L, M, 14 * D, device=device, dtype=torch.bfloat16),   # xn1 | qkv | a | xn2 | h | g
+            xs=torch.empty(L, 2, M, D, device=device, dtype=torch.float32),      # x_in, x_mid
+            st=torch.empty(L, 4, M, device=device, dtype=torch.float32),         # mean1 rstd1 mean2 rstd2
+            lse=torch.empty(L, B, H, T, device=device, dtype=torch.float32),
+            out=torch.empty(M, D, device=device, dtype=torch.float32), B=B, key_keep=None)
+
+    def forward(self, x: torch.Tensor, B: int, *, saved: Optional[dict] = None,
+                key_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: fp32 [B*T, D] residual stream entering block 0; returns the stream leaving the last block.
+        saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0]."""
+        geo = self.geo
+        D, T, H = geo.width, geo.tokens, geo.heads
+        M = B * T
+        L = len(self.blocks)
+        dev = x.device
+        kc = geo.linear_layout
+        train = saved is not None
+        if train:
+            assert x.data_ptr() == saved["xs"][0, 0].data_ptr()
+            bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
+            saved["key_keep"] = key_keep
+        else:
+            bf = torch.empty(M, 10 * D, device=dev, dtype=torch.bfloat16)      # xn | qkv | a | - | g  (reused per layer)
+        for l, w in enumerate(self.blocks):
+            if train:
+                row = bf[l]
+                xn1, qkv, a = row[:, 0:D], row[:, D:4 * D], row[:, 4 * D:5 * D]
+                xn2, h, g = row[:, 5 * D:6 * D], row[:, 6 * D:10 * D], row[:, 10 * D:14 * D]
+                x_in, x_mid = xs[l, 0], xs[l, 1]
+                x_out = xs[l + 1, 0] if l + 1 < L else saved["out"]
+                m1, r1, m2, r2 = st[l, 0], st[l, 1], st[l, 2], st[l, 3]
+                lse_l = lse[l]
+            else:
+                xn1, qkv, a, g = bf[:, 0:D], bf[:, D:4 * D], bf[:, 4 * D:5 * D], bf[:, 6 * D:10 * D]
+                xn2, h = xn1, None
+                x_in = x_mid = x_out = x
+                m1 = r1 = m2 = r2 = lse_l = None
+            ops.layernorm_fwd(x_in, w.ln1_w, w.ln1_b, rows=M, out_bf16=xn1, mean=m1, rstd=r1)
+            ops.gemm_bf16(xn1, w.w_qkv, b_kcontig=kc, bias=w.b_qkv, out_bf16=qkv, M=M)
+            ops.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H, causal=geo.causal,
+                              key_keep=key_keep, lse=lse_l)
+            ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in, out_f32=x_mid, M=M)
+            ops.layernorm_fwd(x_mid, w.ln2_w, w.ln2_b, rows=M, out_bf16=xn2, mean=m2, rstd=r2)
+            ops.gemm_bf16(xn2, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, out_pre=h, M=M)
+            ops.gemm_bf16(g, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=x_mid, out_f32=x_out, M=M)
+            x = x_out
+        return x
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool):
+        """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out]."""
+        a, b = (dy, xin) if self.geo.linear_layout else (xin, dy)
+        n_out, k_in = gw.shape
+        splits = wgrad_splits(n_out, k_in, M)
+        ws = self.scratch.floats(splits * n_out * k_in) if splits > 1 else None
+        ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
+                      split_k=splits, split_ws=ws)
+
+    def _bgrad(self, dy: torch.Tensor, gb: torch.Tensor, M: int, acc: bool):
+        C = gb.numel()
+        ws = self.scratch.floats(ops.colsum_ws_floats(M, C))
+        ops.colsum(dy, gb, ws, R=M, C=C, ld=dy.stride(0), accumulate=acc)
+
+    def backward(self, dx: torch.Tensor, dxb: torch.Tensor, saved: dict, acc: Dict[int, bool]):
+        """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the stack output, [B*T, D]; both are updated
+        in place layer by layer and on return hold the gradient w.r.t. the stack input.
+        acc[id(grad_tensor)] says whether that grad buffer already holds a gradient to add to."""
+        geo = self.geo
+        D, T, H = geo.width, geo.tokens, geo.heads
+        B = saved["B"]
+        M = B * T
+        dev = dx.device
+        kc = geo.linear_layout
+        dact = _DACT[geo.act]
+        bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
+        tmp = torch.empty(M, 8 * D, device=dev, dtype=torch.bfloat16)      # dh | dqkv | dxn / da
+        dh, dqkv, dsm = tmp[:, 0:4 * D], tmp[:, 4 * D:7 * D], tmp[:, 7 * D:8 * D]
+        ln_ws = self.scratch  # partial sums live in scratch; sized per call
+        for l in range(len(self.blocks) - 1, -1, -1):
+            w = self.blocks[l]
+            gr = w.grads
+            row = bf[l]
+            xn1, qkv, a = row[:, 0:D], row[:, D:4 * D], row[:, 4 * D:5 * D]
+            xn2, h, g = row[:, 5 * D:6 * D], row[:, 6 * D:10 * D], row[:, 10 * D:14 * D]
+            x_in, x_mid = xs[l, 0], xs[l, 1]
+            m1, r1, m2, r2 = st[l, 0], st[l, 1], st[l, 2], st[l, 3]
+
+            def A(name):
+                t = gr[name]
+                return acc.get(id(t), False)
+
+            # ---- MLP branch ----
+            if gr is not None:
+                self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj"))
+                self._bgrad(dxb, gr["b_proj"], M, A("b_proj"))
+            ops.gemm_bf16(dxb, w.w_proj, b_kcontig=not kc, act=dact, aux=h, out_bf16=dh, M=M)
+            if gr is not None:
+                self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc"))
+                self._bgrad(dh, gr["b_fc"], M, A("b_fc"))
+            ops.gemm_bf16(dh, w.w_fc, b_kcontig=not kc, out_bf16=dsm, M=M)
+            ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
+            ops.layernorm_bwd(dsm, x_mid, w.ln2_w, m2, r2, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb,
+                              dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
+                              accumulate=A("ln2_w") if gr is not None else False, ws=ws)
+            # ---- attention branch ----
+            if gr is not None:
+                self._wgrad(dxb, a, gr["w_o"], M, A("w_o"))
+                self._bgrad(dxb, gr["b_o"], M, A("b_o"))
+            ops.gemm_bf16(dxb, w.w_o, b_kcontig=not kc, out_bf16=dsm, M=M)
+            ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
+                              dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
+                              key_keep=saved["key_keep"])
+            if gr is not None:
+                self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv"))
+                self._bgrad(dqkv, gr["b_qkv"], M, A("b_qkv"))
+            ops.gemm_bf16(dqkv, w.w_qkv, b_kcontig=not kc, out_bf16=dsm, M=M)
+            ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
+            ops.layernorm_bwd(dsm, x_in, w.ln1_w, m1, r1, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb,
+                              dgamma=gr["ln1_w"] if gr is not None else None, dbeta=gr["ln1_b"] if gr is not None else None,
+                              accumulate=A("ln1_w") if gr is not None else False, ws=ws)

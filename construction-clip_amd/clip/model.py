@@ -1,0 +1,425 @@
+"""`CLIP` - the nn.Module the reference's scripts get from `clip.load()` and call as
+`model(image, text)`, `model.encode_image`, `model.encode_text`
+(/root/reference/CLIP/train.py:105,161; /root/reference/CLIP/predict.py:12,46;
+/root/reference/CLIP_prefix_caption/parse_coco.py:20,43,45,50), rebuilt MI355X-first.
+
+Same module tree and state_dict keys as openai/CLIP, so checkpoints written by
+`torch.save(model.state_dict())` (CLIP/train.py:213-217) load unchanged - but the modules are
+parameter holders only: all arithmetic is a hand-scheduled sequence of HIP launches
+(cclip_hip.stack / libcclip_hip.so) wrapped in three autograd nodes (image tower, text tower,
+logits).  There is no torch fallback: on a non-CUDA device forward raises.
+
+Precision: fp32 master weights in a flat arena, bf16 MFMA operands with fp32 accumulation,
+fp32 residual stream and LayerNorm statistics, exact-fp32 pooled projections / normalise / logits.
+(The reference's CUDA path is plain fp16 weights; bf16 + fp32 masters is the
+MI355X-native counterpart.)
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from cclip_hip import ops
+from cclip_hip.arena import ParamArena
+from cclip_hip.stack import BlockStack, BlockWeights, Scratch, StackGeometry
+
+from .weights import CLIPGeometry, geometry_from_state_dict
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders (OpenAI key layout)
+# ------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__} is a parameter holder; run the model through "
+                           "CLIP.encode_image / encode_text / forward (HIP path)")
+
+
+class LayerNorm(_Holder):
+    def __init__(self, width: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(width))
+        self.bias = nn.Parameter(torch.zeros(width))
+
+
+class Linear(_Holder):
+    def __init__(self, n_in: int, n_out: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in))
+        self.bias = nn.Parameter(torch.zeros(n_out))
+
+
+class MultiheadAttention(_Holder):
+    def __init__(self, width: int, heads: int):
+        super().__init__()
+        self.num_heads = heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.out_proj = Linear(width, width)
+
+
+class MLP(_Holder):
+    def __init__(self, width: int):
+        super().__init__()
+        self.c_fc = Linear(width, 4 * width)
+        self.c_proj = Linear(4 * width, width)
+
+
+class ResidualAttentionBlock(_Holder):
+    def __init__(self, width: int, heads: int):
+        super().__init__()
+        self.ln_1 = LayerNorm(width)
+        self.attn = MultiheadAttention(width, heads)
+        self.ln_2 = LayerNorm(width)
+        self.mlp = MLP(width)
+
+
+class Transformer(_Holder):
+    def __init__(self, width: int, layers: int, heads: int):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+
+class Conv2d(_Holder):
+    def __init__(self, width: int, patch: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(width, 3, patch, patch))
+
+
+class Embedding(_Holder):
+    def __init__(self, vocab: int, width: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(vocab, width))
+
+
+class VisionTransformer(_Holder):
+    def __init__(self, geo: CLIPGeometry):
+        super().__init__()
+        w = geo.vision_width
+        self.input_resolution, self.output_dim = geo.image_resolution, geo.embed_dim
+        self.conv1 = Conv2d(w, geo.vision_patch_size)
+        self.class_embedding = nn.Parameter(torch.empty(w))
+        self.positional_embedding = nn.Parameter(torch.empty(geo.vision_tokens, w))
+        self.ln_pre = LayerNorm(w)
+        self.transformer = Transformer(w, geo.vision_layers, geo.vision_heads)
+        self.ln_post = LayerNorm(w)
+        self.proj = nn.Parameter(torch.empty(w, geo.embed_dim))
+
+
+_BLOCK_KEYS = {"ln1_w": "ln_1.weight", "ln1_b": "ln_1.bias", "w_qkv": "attn.in_proj_weight", "b_qkv": "attn.in_proj_bias",
+               "w_o": "attn.out_proj.weight", "b_o": "attn.out_proj.bias", "ln2_w": "ln_2.weight", "ln2_b": "ln_2.bias",
+               "w_fc": "mlp.c_fc.weight", "b_fc": "mlp.c_fc.bias", "w_proj": "mlp.c_proj.weight", "b_proj": "mlp.c_proj.bias"}
+_MATS = ("w_qkv", "w_o", "w_fc", "w_proj")
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: this CLIP runs on MI355X HIP kernels only; got a {t.device} tensor "
+                           "(there is deliberately no CPU/eager fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+class CLIP(nn.Module):
+    def __init__(self, geo: CLIPGeometry):
+        super().__init__()
+        self.geo = geo
+        self.context_length = geo.context_length
+        self.vocab_size = geo.vocab_size
+        self.visual = VisionTransformer(geo)
+        self.transformer = Transformer(geo.transformer_width, geo.transformer_layers, geo.transformer_heads)
+        self.token_embedding = Embedding(geo.vocab_size, geo.transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(geo.context_length, geo.transformer_width))
+        self.ln_final = LayerNorm(geo.transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(geo.transformer_width, geo.embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+        self._arena: Optional[ParamArena] = None
+        self._rt: Optional[dict] = None
+
+    # -- nn.Module plumbing ---------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)      # .to()/.cuda()/.half() re-point parameters: rebuild lazily
+        self._arena, self._rt = None, None
+        return out
+
+    def float(self):          # masters are always fp32; nothing to convert
+        return self
+
+    def half(self):           # the reference's fp16 CUDA weights map to bf16 shadows here
+        return self
+
+    @property
+    def arena(self) -> ParamArena:
+        self._ensure_runtime()
+        return self._arena
+
+    def _ensure_runtime(self):
+        dev = self.logit_scale.device
+        if dev.type != "cuda":
+            raise RuntimeError("CLIP parameters are on %s; move the model to the GPU (model.to('cuda')) - "
+                               "the HIP kernels are the only compute path" % dev)
+        if self._arena is not None and self._arena.intact():
+            return
+        ar = ParamArena(self, dev)
+        geo = self.geo
+
+        def stack(prefix: str, width: int, heads: int, layers: int, tokens: int, causal: bool) -> BlockStack:
+            blocks: List[BlockWeights] = []
+            for i in range(layers):
+                kw, grads = {}, {}
+                for f, key in _BLOCK_KEYS.items():
+                    name = f"{prefix}.resblocks.{i}.{key}"
+                    kw[f] = ar.b[name] if f in _MATS else ar.params[name].data
+                    grads[f] = ar.g[name]
+                blocks.append(BlockWeights(grads=grads, **kw))
+            return BlockStack(StackGeometry(width, heads, tokens, True, ops.ACT_QUICKGELU, causal), blocks, Scratch(dev))
+
+        self._arena = ar
+        self._rt = dict(
+            vis=stack("visual.transformer", geo.vision_width, geo.vision_heads, geo.vision_layers, geo.vision_tokens, False),
+            txt=stack("transformer", geo.transformer_width, geo.transformer_heads, geo.transformer_layers,
+                      geo.context_length, True),
+            vis_names=[n for n in ar.names if n.startswith("visual.")],
+            txt_names=[n for n in ar.names if not n.startswith("visual.") and n != "logit_scale"],
+        )
+
+    def initialize_parameters(self, seed: int = 567, finetuned_like: bool = True):
+        from .weights import init_state_dict
+        self.load_state_dict(init_state_dict(self.geo, seed, finetuned_like))
+        return self
+
+    # -- image tower ----------------------------------------------------------------------------
+    def _image_forward(self, image: torch.Tensor, train: bool):
+        self._ensure_runtime()
+        ar, geo, st = self._arena, self.geo, self._rt["vis"]
+        ar.refresh_shadows()
+        dev = image.device
+        B, T, D, P = image.shape[0], geo.vision_tokens, geo.vision_width, geo.vision_patch_size
+        if tuple(image.shape[1:]) != (3, geo.image_resolution, geo.image_resolution):
+            raise RuntimeError(f"encode_image: expected [N,3,{geo.image_resolution},{geo.image_resolution}], got {tuple(image.shape)}")
+        M = B * T
+        img = image.detach().to(torch.float32).contiguous()
+        patches = torch.empty(M, 3 * P * P, device=dev, dtype=torch.bfloat16)
+        ops.patchify(img, patches, P)
+        patch_out = torch.empty(M, D, device=dev, dtype=torch.float32)
+        ops.gemm_bf16(patches, ar.b["visual.conv1.weight"].view(D, -1), out_f32=patch_out)
+        p = ar.params
+        saved = st.alloc_saved(B, dev) if train else None
+        x = saved["xs"][0, 0] if train else torch.empty(M, D, device=dev, dtype=torch.float32)
+        x0 = torch.empty(M, D, device=dev, dtype=torch.float32) if train else None
+        st0 = torch.empty(2, M, device=dev, dtype=torch.float32) if train else None
+        ops.vit_embed_ln(patch_out, p["visual.class_embedding"].data, p["visual.positional_embedding"].data,
+                         p["visual.ln_pre.weight"].data, p["visual.ln_pre.bias"].data, x, rows=M, T=T, x0=x0,
+                         mean=st0[0] if train else None, rstd=st0[1] if train else None)
+        xo = st.forward(x, B, saved=saved)
+        rows = (torch.arange(B, device=dev, dtype=torch.int32) * T).contiguous()
+        pooled = torch.empty(B, D, device=dev, dtype=torch.float32)
+        stp = torch.empty(2, B, device=dev, dtype=torch.float32)
+        ops.layernorm_fwd(xo, p["visual.ln_post.weight"].data, p["visual.ln_post.bias"].data, rows=B, row_index=rows,
+                          out_f32=pooled, mean=stp[0], rstd=stp[1])
+        feat = torch.empty(B, geo.embed_dim, device=dev, dtype=torch.float32)
+        ops.gemm_f32(pooled, p["visual.proj"].data.t(), feat)
+        ctx = dict(saved=saved, patches=patches, x0=x0, st0=st0, xo=xo, rows=rows, pooled=pooled, stp=stp, B=B) if train else None
+        return feat, ctx
+
+    def _image_backward(self, c: dict, dfeat: torch.Tensor):
+        ar, geo, st = self._arena, self.geo, self._rt["vis"]
+        p, g = ar.params, ar.g
+        acc = ar.begin_backward()
+        B, T, D = c["B"], geo.vision_tokens, geo.vision_width
+        M = B * T
+        dev = dfeat.device
+        dfeat = dfeat.contiguous().float()
+
+        def A(name):
+            return acc[id(g[name])]
+
+        ops.gemm_f32(c["pooled"].t(), dfeat.t(), g["visual.proj"], beta=1.0 if A("visual.proj") else 0.0)
+        dpooled = torch.empty(B, D, device=dev, dtype=torch.float32)
+        ops.gemm_f32(dfeat, p["visual.proj"].data, dpooled)
+        dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
+        dxb = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+        sc = st.scratch
+        ops.layernorm_bwd(dpooled, c["xo"], p["visual.ln_post.weight"].data, c["stp"][0], c["stp"][1], rows=B,
+                          row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["visual.ln_post.weight"],
+                          dbeta=g["visual.ln_post.bias"], accumulate=A("visual.ln_post.weight"),
+                          ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
+        st.backward(dx, dxb, c["saved"], acc)
+        ops.layernorm_bwd(dx, c["x0"], p["visual.ln_pre.weight"].data, c["st0"][0], c["st0"][1], rows=M, dx_out=dx,
+                          dx_out_bf16=dxb, dgamma=g["visual.ln_pre.weight"], dbeta=g["visual.ln_pre.bias"],
+                          accumulate=A("visual.ln_pre.weight"), ws=sc.floats(ops.layernorm_bwd_ws_floats(M, D)))
+        # x0 = patch_out + positional (+ class on slot 0): batch sums of dx0 viewed [B, T*D]
+        ops.colsum(dx, g["visual.positional_embedding"], sc.floats(ops.colsum_ws_floats(B, T * D)), R=B, C=T * D,
+                   ld=T * D, accumulate=A("visual.positional_embedding"))
+        ops.colsum(dx, g["visual.class_embedding"], sc.floats(ops.colsum_ws_floats(B, D)), R=B, C=D, ld=T * D,
+                   accumulate=A("visual.class_embedding"))
+        st._wgrad(dxb, c["patches"], g["visual.conv1.weight"].view(D, -1), M, A("visual.conv1.weight"))
+        ar.publish_grads(self._rt["vis_names"])
+
+    # -- text tower -----------------------------------------------------------------------------
+    def _text_forward(self, text: torch.Tensor, train: bool):
+        self._ensure_runtime()
+        ar, geo, st = self._arena, self.geo, self._rt["txt"]
+        ar.refresh_shadows()
+        dev = text.device
+        if text.dim() != 2 or text.shape[1] != geo.context_length:
+            raise RuntimeError(f"encode_text: expected [N,{geo.context_length}] token ids, got {tuple(text.shape)}")
+        B, L, D = text.shape[0], geo.context_length, geo.transformer_width
+        M = B * L
+        tok = text.detach().to(torch.int32).contiguous()
+        p = ar.params
+        saved = st.alloc_saved(B, dev) if train else None
+        x = saved["xs"][0, 0] if train else torch.empty(M, D, device=dev, dtype=torch.float32)
+        ops.text_embed(tok.view(-1), p["token_embedding.weight"].data, p["positional_embedding"].data, x, rows=M, L=L)
+        xo = st.forward(x, B, saved=saved)
+        # EOT = largest id in the row (openai/CLIP: x[arange, text.argmax(-1)]); integer index math only
+        rows = (torch.arange(B, device=dev) * L + text.detach().argmax(dim=-1)).to(torch.int32).contiguous()
+        pooled = torch.empty(B, D, device=dev, dtype=torch.float32)
+        stp = torch.empty(2, B, device=dev, dtype=torch.float32)
+        ops.layernorm_fwd(xo, p["ln_final.weight"].data, p["ln_final.bias"].data, rows=B, row_index=rows, out_f32=pooled,
+                          mean=stp[0], rstd=stp[1])
+        feat = torch.empty(B, geo.embed_dim, device=dev, dtype=torch.float32)
+        ops.gemm_f32(pooled, p["text_projection"].data.t(), feat)
+        ctx = dict(saved=saved, tok=tok, xo=xo, rows=rows, pooled=pooled, stp=stp, B=B) if train else None
+        return feat, ctx
+
+    def _text_backward(self, c: dict, dfeat: torch.Tensor):
+        ar, geo, st = self._arena, self.geo, self._rt["txt"]
+        p, g = ar.params, ar.g
+        acc = ar.begin_backward()
+        B, L, D = c["B"], geo.context_length, geo.transformer_width
+        M = B * L
+        dev = dfeat.device
+        dfeat = dfeat.contiguous().float()
+
+        def A(name):
+            return acc[id(g[name])]
+
+        ops.gemm_f32(c["pooled"].t(), dfeat.t(), g["text_projection"], beta=1.0 if A("text_projection") else 0.0)
+        dpooled = torch.empty(B, D, device=dev, dtype=torch.float32)
+        ops.gemm_f32(dfeat, p["text_projection"].data, dpooled)
+        dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
+        dxb = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+        sc = st.scratch
+        ops.layernorm_bwd(dpooled, c["xo"], p["ln_final.weight"].data, c["stp"][0], c["stp"][1], rows=B,
+                          row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["ln_final.weight"],
+                          dbeta=g["ln_final.bias"], accumulate=A("ln_final.weight"),
+                          ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
+        st.backward(dx, dxb, c["saved"], acc)
+        ops.colsum(dx, g["positional_embedding"], sc.floats(ops.colsum_ws_floats(B, L * D)), R=B, C=L * D, ld=L * D,
+                   accumulate=A("positional_embedding"))
+        if not A("token_embedding.weight"):
+            g["token_embedding.weight"].zero_()
+        ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M)
+        ar.publish_grads(self._rt["txt_names"])
+
+    # -- public API (same names / argument meaning as openai/CLIP) --------------------------------
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        _require_cuda(image, "encode_image")
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.visual.parameters()):
+            self._ensure_runtime()
+            return _ImageTower.apply(self, image, *[self._arena.params[n] for n in self._rt["vis_names"]])
+        return self._image_forward(image, train=False)[0]
+
+    def encode_text(self, text: torch.Tensor) -> torch.Tensor:
+        _require_cuda(text, "encode_text")
+        self._ensure_runtime()
+        names = self._rt["txt_names"]
+        if torch.is_grad_enabled() and any(self._arena.params[n].requires_grad for n in names):
+            return _TextTower.apply(self, text, *[self._arena.params[n] for n in names])
+        return self._text_forward(text, train=False)[0]
+
+    def forward(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        fi = self.encode_image(image)
+        ft = self.encode_text(text)
+        logits_per_image = _Logits.apply(fi, ft, self.logit_scale)
+        return logits_per_image, logits_per_image.t()
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd nodes: forward = kernel sequence; backward = hand-written kernel sequence that writes the
+# arena's gradient slots directly (parameter inputs get None back; .grad is pointed at the slots).
+# ------------------------------------------------------------------------------------------------
+class _ImageTower(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: CLIP, image, *params):
+        feat, c = model._image_forward(image, train=True)
+        ctx.model, ctx.c, ctx.n = model, c, len(params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        ctx.model._image_backward(ctx.c, dfeat)
+        ctx.c = None
+        return (None, None) + (None,) * ctx.n
+
+
+class _TextTower(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: CLIP, text, *params):
+        feat, c = model._text_forward(text, train=True)
+        ctx.model, ctx.c, ctx.n = model, c, len(params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        ctx.model._text_backward(ctx.c, dfeat)
+        ctx.c = None
+        return (None, None) + (None,) * ctx.n
+
+
+def normalized_logits(fi: torch.Tensor, ft: torch.Tensor, logit_scale: torch.Tensor):
+    """L2-normalise both feature sets and form exp(logit_scale) * I @ T^T in exact fp32 (kernels only)."""
+    dev = fi.device
+    Ni, E = fi.shape
+    Nt = ft.shape[0]
+    i_n, t_n = torch.empty_like(fi), torch.empty_like(ft)
+    inv_i = torch.empty(Ni, device=dev, dtype=torch.float32)
+    inv_t = torch.empty(Nt, device=dev, dtype=torch.float32)
+    ops.l2norm_fwd(fi, i_n, inv_i)
+    ops.l2norm_fwd(ft, t_n, inv_t)
+    logits = torch.empty(Ni, Nt, device=dev, dtype=torch.float32)
+    ops.gemm_f32(i_n, t_n, logits, alpha_log_dev=logit_scale)
+    return logits, i_n, t_n, inv_i, inv_t
+
+
+class _Logits(torch.autograd.Function):
+    """CLIP.forward's tail (openai/CLIP; call sites CLIP/train.py:161, CLIP/predict.py:46)."""
+
+    @staticmethod
+    def forward(ctx, fi, ft, logit_scale):
+        fi, ft = fi.contiguous().float(), ft.contiguous().float()
+        ls = logit_scale.detach().float().reshape(1).contiguous()
+        logits, i_n, t_n, inv_i, inv_t = normalized_logits(fi, ft, ls)
+        ctx.saved = (i_n, t_n, inv_i, inv_t, ls, logits)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        i_n, t_n, inv_i, inv_t, ls, logits = ctx.saved
+        dl = dlogits.contiguous().float()
+        d_in, d_tn = torch.empty_like(i_n), torch.empty_like(t_n)
+        ops.gemm_f32(dl, t_n.t(), d_in, alpha_log_dev=ls)          # s * dL @ Tn
+        ops.gemm_f32(dl.t(), i_n.t(), d_tn, alpha_log_dev=ls)      # s * dL^T @ In
+        dfi, dft = torch.empty_like(i_n), torch.empty_like(t_n)
+        ops.l2norm_bwd(d_in, i_n, inv_i, dfi)
+        ops.l2norm_bwd(d_tn, t_n, inv_t, dft)
+        dscale = torch.empty(1, device=dl.device, dtype=torch.float32)
+        ops.reduce_dot(dl, logits, dscale)                          # d/d(log s) of s*C = logits
+        ctx.saved = None
+        return dfi, dft, dscale.reshape(())
+
+
+def build_model(state_dict: Dict[str, torch.Tensor]) -> CLIP:
+    """openai/CLIP's build_model(): geometry from tensor shapes, then load (CLIP/train.py:111 round trip)."""
+    sd = {k: v for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+    model = CLIP(geometry_from_state_dict(sd))
+    model.load_state_dict(sd)
+    return model.eval()

@@ -125,46 +125,67 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int* __res
   }
 }
 
-// column sums, two deterministic passes: part[rs][c] then out[c].  4 columns per lane.
+// column sums, two deterministic passes: part[rs][c] then out[c].  8 columns (16 B of bf16) per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ in, long ld, int R, int C,
                                                              float* __restrict__ part) {
-  __shared__ float red[4][256];
+  __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 256 + lane * 4;
+  const int col = blockIdx.x * 512 + lane * 8;
   const int rs = blockIdx.y, nrs = gridDim.y;
   const int r_per = (R + nrs - 1) / nrs;
   const int r0 = rs * r_per, r1 = (r0 + r_per < R) ? r0 + r_per : R;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (col < C) {
+    const bool full = col + 8 <= C;                      // C % 4 == 0: a lane is full or half
     for (int r = r0 + wave; r < r1; r += 4) {
       if constexpr (sizeof(T) == 2) {
-        const bf16x4 t = *(const bf16x4*)((const bf16*)in + (long)r * ld + col);
-        acc.x += (float)t[0]; acc.y += (float)t[1]; acc.z += (float)t[2]; acc.w += (float)t[3];
+        const bf16* p = (const bf16*)in + (long)r * ld + col;
+        if (full) {
+          const bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)t[j];
+        } else {
+          const bf16x4 t = *(const bf16x4*)p;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += (float)t[j];
+        }
       } else {
-        const float4 t = *(const float4*)((const float*)in + (long)r * ld + col);
-        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        const float* p = (const float*)in + (long)r * ld + col;
+        const float4 a = *(const float4*)p;
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        if (full) {
+          const float4 b = *(const float4*)(p + 4);
+          acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        }
       }
     }
   }
-  *(float4*)&red[wave][lane * 4] = acc;
-  __syncthreads();
-  if (wave == 0 && col < C) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float4 t = *(const float4*)&red[w][lane * 4];
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-    }
-    *(float4*)(part + (long)rs * C + col) = s;
+  for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = acc[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int c = blockIdx.x * 512 + i;
+    if (c < C) part[(long)rs * C + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nrs, int C, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] (+)= sum_rs part[rs][c]; block = 32 columns x 8 row groups, fixed order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nrs, int C,
+                                                           float* __restrict__ out, int accumulate) {
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int r = 0; r < nrs; ++r) s += part[(long)r * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (col < C)
+    for (int r = rg; r < nrs; r += 8) s += part[(long)r * C + col];
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && col < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    out[col] = accumulate ? out[col] + t : t;
+  }
 }
 
 static int grid_rows4(int rows) { int g = (rows + 3) / 4; return g > 4096 ? 4096 : (g < 1 ? 1 : g); }
@@ -204,17 +225,26 @@ extern "C" int cclip_embed_scatter_add(const int32_t* text, const float* dx, int
   return cclip_launch_status();
 }
 
-static int colsum_splits(int R) { int s = (R + 127) / 128; return s > 64 ? 64 : (s < 1 ? 1 : s); }
-extern "C" int cclip_colsum_ws_floats(int32_t R, int32_t C) { return colsum_splits(R) * C; }
+// row splits: enough blocks (~2048) to saturate HBM whatever the column count, >= 32 rows per split
+static int colsum_splits(int R, int C) {
+  const int cb = (C + 511) / 512;
+  int s = (2048 + cb - 1) / cb;
+  const int smax = (R + 31) / 32;
+  if (s > smax) s = smax;
+  if (s > 1024) s = 1024;
+  return s < 1 ? 1 : s;
+}
+extern "C" int cclip_colsum_ws_floats(int32_t R, int32_t C) { return colsum_splits(R, C) * C; }
 extern "C" int cclip_colsum(const void* in, int32_t in_is_bf16, int64_t ld, int32_t R, int32_t C, float* out,
                             int32_t accumulate, float* ws, hipStream_t stream) {
   if (!in || !out || !ws || R <= 0 || C <= 0 || (C & 3) || (ld & 3)) return CCLIP_ERR_ARG;
-  const int nrs = colsum_splits(R);
-  dim3 grid((C + 255) / 256, nrs), block(256);
+  if (in_is_bf16 ? ((ld & 7) || ((uintptr_t)in & 15)) : ((uintptr_t)in & 15)) return CCLIP_ERR_ARG;
+  const int nrs = colsum_splits(R, C);
+  dim3 grid((C + 511) / 512, nrs), block(256);
   if (in_is_bf16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, block, 0, stream, (const bf16*)in, (long)ld, R, C, ws);
   else hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, stream, (const float*)in, (long)ld, R, C, ws);
   int st = cclip_launch_status();
   if (st != CCLIP_OK) return st;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, nrs, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, ws, nrs, C, out, accumulate);
   return cclip_launch_status();
 }

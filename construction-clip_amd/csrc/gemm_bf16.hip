@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 extern "C" int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream) {
   if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return CCLIP_ERR_ARG;
-  if ((d->K & 7) || (d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
+  if ((d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
+  if ((d->a_kcontig || d->b_kcontig) && (d->K & 7)) return CCLIP_ERR_ARG;   // K-strided operands take any K
   if (!d->a_kcontig && (d->M & 7)) return CCLIP_ERR_ARG;
   if (!d->a_kcontig && d->b_kcontig) return CCLIP_ERR_ARG;   // (0,1) is not a layout this path uses
   if ((uintptr_t)d->A & 15 || (uintptr_t)d->B & 15) return CCLIP_ERR_ARG;

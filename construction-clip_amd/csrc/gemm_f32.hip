@@ -20,7 +20,8 @@
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
                                                        const float* __restrict__ B, long sbn, long sbk, int M, int N,
-                                                       int K, float alpha, float beta, float* __restrict__ C, long ldc) {
+                                                       int K, float alpha, const float* __restrict__ alpha_log_dev, float beta,
+                                                       float* __restrict__ C, long ldc) {
   __shared__ float As[FBM * FLD], Bs[FBN * FLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
     __syncthreads();
   }
+  if (alpha_log_dev) alpha *= __expf(*alpha_log_dev);
   // D[i = 4g + r][j = li]: i <-> n (from the B-side operand), j <-> m
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -87,11 +89,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 extern "C" int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
-                              int32_t M, int32_t N, int32_t K, float alpha, float beta, float* C, int64_t ldc,
-                              hipStream_t stream) {
+                              int32_t M, int32_t N, int32_t K, float alpha, const float* alpha_log_dev, float beta, float* C,
+                              int64_t ldc, hipStream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return CCLIP_ERR_ARG;
   dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM), block(256);
   hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, stream, A, (long)sam, (long)sak, B, (long)sbn, (long)sbk, M, N, K,
-                     alpha, beta, C, (long)ldc);
+                     alpha, alpha_log_dev, beta, C, (long)ldc);
   return cclip_launch_status();
 }

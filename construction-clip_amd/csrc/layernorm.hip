@@ -156,16 +156,29 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const DY* __restr
   }
 }
 
-// column sums of part[nblk][2][D] -> dgamma[D] (+=), dbeta[D] (+=)
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * D) return;
-  const int which = i / D, col = i % D;
+// column sums of part[nblk][2][D] -> dgamma[D], dbeta[D].  Block = 32 columns x 8 row groups; fixed
+// summation order -> deterministic.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + c;                 // column in [0, 2D)
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[((long)b * 2 + which) * D + col];
-  float* dst = which == 0 ? dgamma : dbeta;
-  dst[col] = accumulate ? dst[col] + s : s;
+  if (i < 2 * D) {
+    const int which = i / D, col = i % D;
+    for (int b = rg; b < nblk; b += 8) s += part[((long)b * 2 + which) * D + col];
+  }
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && i < 2 * D) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    const int which = i / D, col = i % D;
+    float* dst = which == 0 ? dgamma : dbeta;
+    dst[col] = accumulate ? dst[col] + t : t;
+  }
 }
 
 static int ln_grid(int rows) {
@@ -186,7 +199,8 @@ extern "C" int cclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* r
   return cclip_launch_status();
 }
 
-extern "C" int cclip_layernorm_bwd_ws_floats(int32_t rows, int32_t D) { return ln_grid(rows > 8192 ? 8192 : rows) * 2 * D; }
+static int ln_bwd_grid(int rows) { int g = ln_grid(rows); return g > 1024 ? 1024 : g; }
+extern "C" int cclip_layernorm_bwd_ws_floats(int32_t rows, int32_t D) { return ln_bwd_grid(rows) * 2 * D; }
 
 extern "C" int cclip_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx,
                                    const int32_t* row_index, int32_t rows, int32_t D, const float* gamma,
@@ -198,7 +212,7 @@ extern "C" int cclip_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t l
   if ((dgamma || dbeta) && !(dgamma && dbeta && ws)) return CCLIP_ERR_ARG;
   const int nv = (D + 255) / 256;
   // parameter-grad partials: cap the grid so the partial buffer stays small (<= 2048 blocks x 2 x D)
-  const int nblk = ln_grid(rows > 8192 ? 8192 : rows);
+  const int nblk = ln_bwd_grid(rows);
   dim3 grid(nblk), block(64 * LN_WAVES);
   float* part = dgamma ? ws : nullptr;
 #define LNB(NV, T) hipLaunchKernelGGL((ln_bwd_kernel<NV, T>), grid, block, 0, stream, (const T*)dy, (long)lddy, x, (long)ldx, row_index, rows, D, gamma, mean, rstd, dx_res, dx_out, (bf16*)dx_out_bf16, (long)lddx, part)
@@ -207,6 +221,6 @@ extern "C" int cclip_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t l
 #undef LNB
   int st = cclip_launch_status();
   if (st != CCLIP_OK || !dgamma) return st;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, ws, nblk, D, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, stream, ws, nblk, D, dgamma, dbeta, accumulate);
   return cclip_launch_status();
 }

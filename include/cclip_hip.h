@@ -48,7 +48,8 @@ enum {
  * Replaces nn.Linear / nn.MultiheadAttention projections / Conv1D / lm_head matmuls and their
  * dgrad + wgrad.  a_kcontig: A(m,k) at A[m*lda+k] (1) or A[k*lda+m] (0); b_kcontig: B(n,k) at
  * B[n*ldb+k] (1) or B[k*ldb+n] (0).  Supported (a,b): (1,1) forward, (1,0) dgrad / Conv1D,
- * (0,0) wgrad.  Contract: K, N, lda, ldb, ldc multiples of 8; M multiple of 8 when a_kcontig=0;
+ * (0,0) wgrad.  Contract: N, lda, ldb, ldc multiples of 8; K multiple of 8 unless both operands are
+ * K-strided (wgrad: any token count); M multiple of 8 when a_kcontig=0;
  * A and B 16-byte aligned.  Epilogue order: *alpha, +bias[n], (store out_pre_bf16), act,
  * +residual[m][n] (fp32, may alias out_f32), store out_f32 and/or out_bf16.
  * split_k > 1: K is cut into split_k ranges whose fp32 partial tiles go to split_ws
@@ -117,12 +118,13 @@ int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream);
 
 /* ---- exact fp32 GEMM (f32-input MFMA), generic strides ---------------------------------------
- * C[m*ldc+n] = alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m*ldc+n].
+ * C[m*ldc+n] = alpha' * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m*ldc+n], with
+ * alpha' = alpha * (alpha_log_dev ? exp(*alpha_log_dev) : 1)  (logit_scale.exp() without a host sync).
  * Replaces `x @ visual.proj`, `x @ text_projection`, `logit_scale.exp() * I @ T.t()` of
  * CLIP.forward/encode_* and their backward products (tiny, accuracy critical). */
 int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
-                   int32_t M, int32_t N, int32_t K, float alpha, float beta, float* C, int64_t ldc,
-                   hipStream_t stream);
+                   int32_t M, int32_t N, int32_t K, float alpha, const float* alpha_log_dev, float beta,
+                   float* C, int64_t ldc, hipStream_t stream);
 
 /* ---- embeddings ------------------------------------------------------------------------------
  * cclip_patchify: image fp32 [B,3,R,R] -> bf16 im2col [B*T, 3*P*P], T = (R/P)^2 + 1, class slot
@@ -132,7 +134,8 @@ int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int
  *   x = ln_pre(x0); optional saves x0, mean, rstd.  All fp32 [rows = B*T, D].
  * cclip_text_embed: x[r] = token_embedding[text[r]] + positional_embedding[r % L] (pos may be NULL).
  * cclip_embed_scatter_add: demb[text[r]] += dx[r]   (fp32 atomics).
- * cclip_colsum: out[c] (+)= sum_r in[r*ld + c]; in bf16 or fp32; C % 4 == 0; deterministic;
+ * cclip_colsum: out[c] (+)= sum_r in[r*ld + c]; in bf16 (ld % 8 == 0) or fp32 (ld % 4 == 0), 16-byte
+ *   aligned; C % 4 == 0; deterministic;
  *   ws >= cclip_colsum_ws_floats(R, C) floats. */
 int cclip_patchify(const float* image, void* out_bf16, int32_t B, int32_t R, int32_t P, hipStream_t stream);
 int cclip_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, int32_t rows, int32_t T,
@@ -150,16 +153,22 @@ int cclip_colsum(const void* in, int32_t in_is_bf16, int64_t ld, int32_t R, int3
  * cclip_l2norm_fwd/bwd: y = x / ||x||_2 per row (image_features / image_features.norm(dim=1)).
  * cclip_xent_rows: per row r with label labels[r]: loss_row = logsumexp(row) - row[label]
  *   (0 when label == ignore_index), pred = argmax(row) (first max), and, if dlogits != NULL,
- *   dlogits = (softmax(row) - onehot) * grad_scale (fp32, may alias logits; or bf16, must not).
+ *   dlogits = (softmax(row) - onehot) * grad_scale (fp32, may alias logits; or bf16, must not);
+ *   rowdot (optional) = sum_c dlogits[c] * logits[c]  (the d/d(logit_scale) contribution of the row);
+ *   l2norm_bwd's mul_dev (optional) is a device scalar the result is multiplied by (upstream dloss).
  *   Replaces torch.nn.CrossEntropyLoss + torch.argmax of CLIP/train.py:162-173 and
  *   nnf.cross_entropy(ignore_index=0) of CLIP_prefix_caption/train.py:357. */
 int cclip_l2norm_fwd(const float* x, int64_t ldx, int32_t rows, int32_t D, float* y, int64_t ldy,
                      float* inv_norm, hipStream_t stream);
 int cclip_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* inv_norm,
-                     int32_t rows, int32_t D, float* dx, int64_t lddx, hipStream_t stream);
+                     int32_t rows, int32_t D, float* dx, int64_t lddx, const float* mul_dev,
+                     hipStream_t stream);
 int cclip_xent_rows(const float* logits, int64_t ld, int32_t R, int32_t C, const int32_t* labels,
                     int32_t ignore_index, float grad_scale, float* loss_row, int32_t* pred,
-                    void* dlogits, int32_t dlogits_is_bf16, int64_t ldd, hipStream_t stream);
+                    void* dlogits, int32_t dlogits_is_bf16, int64_t ldd, float* rowdot, hipStream_t stream);
+/* out (+)= alpha * (mul_dev ? *mul_dev : 1) * sum_i a[i] * (b ? b[i] : 1)   (single block, deterministic) */
+int cclip_reduce_dot(const float* a, const float* b, int64_t n, float alpha, const float* mul_dev, float* out,
+                     int32_t accumulate, hipStream_t stream);
 
 /* ---- optimiser over the flat parameter arena -------------------------------------------------
  * mode 0: transformers.AdamW (CLIP/train.py:143): p -= lr*sqrt(bc2)/bc1 * m/(sqrt(v)+eps), then

@@ -181,7 +181,7 @@ def test_patchify_and_embeds():
     close("scatter", demb, ref, 1e-5, 1e-5)
 
 
-@pytest.mark.parametrize("R,C,bf", [(1000, 768, True), (50, 2304, False), (4097, 100, True)])
+@pytest.mark.parametrize("R,C,bf", [(1000, 768, True), (50, 2304, False), (4097, 104, True), (300, 100, False)])
 def test_colsum(R, C, bf):
     o = ops()
     g = G(R)
