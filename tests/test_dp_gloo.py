@@ -1,0 +1,103 @@
+"""CPU, world_size 2 over gloo: the data-parallel contrastive loss of clip/loss.py (embedding all-gather,
+per-rank row blocks, reduce-scatter of cross-rank feature gradients) must equal the single-process loss of
+/root/reference/CLIP/train_caption.py:124-129 on the concatenated batch - value, accuracy count and gradients -
+and clip/parallel.py's bucketed SUM all-reduce must sum the flat gradient arena.  The HIP launchers are replaced
+by tests/cpu_ops_shim.py (torch restatements of their contracts); what is under test is the choreography."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "construction-clip_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import clip.loss as closs
+    import clip.parallel as par
+    import cpu_ops_shim
+    closs.ops = cpu_ops_shim                       # CPU restatement of the launchers (test infrastructure)
+    r, w, _ = par.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(123)
+    N, E = 12, 16
+    fi_all, ft_all = torch.randn(N, E, generator=g), torch.randn(N, E, generator=g)
+    ls = torch.tensor(1.3)
+    nloc = N // world
+    fi = fi_all[rank * nloc:(rank + 1) * nloc].clone().requires_grad_(True)
+    ft = ft_all[rank * nloc:(rank + 1) * nloc].clone().requires_grad_(True)
+    lsp = ls.clone().requires_grad_(True)
+    loss, stats = closs.contrastive_loss(fi, ft, lsp)
+    (loss * 2.0).backward()                        # non-unit upstream gradient
+    # flat-arena all-reduce
+    import clip
+    from clip.weights import MODELS
+    from cclip_hip.arena import ParamArena
+    m = clip.CLIP(MODELS["test-tiny"]).initialize_parameters(1)
+    ar = ParamArena(m, torch.device("cpu"))
+    ar.gflat.copy_(torch.arange(ar.total, dtype=torch.float32) * (rank + 1))
+    par.allreduce_gradients(ar, max_bucket_elems=300_000)
+    torch.save(dict(loss=loss.detach(), stats=stats, dfi=fi.grad, dft=ft.grad, dls=lsp.grad,
+                    gsum_ok=torch.equal(ar.gflat, torch.arange(ar.total, dtype=torch.float32) * 3)),
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp_contrastive_matches_single_process(tmp_path):
+    world, port = 2, 29000 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import clip_oracle as O
+    g = torch.Generator().manual_seed(123)
+    N, E = 12, 16
+    fi = torch.randn(N, E, generator=g).requires_grad_(True)
+    ft = torch.randn(N, E, generator=g).requires_grad_(True)
+    ls = torch.tensor(1.3, requires_grad=True)
+    i_n, t_n = fi / fi.norm(dim=1, keepdim=True), ft / ft.norm(dim=1, keepdim=True)
+    li = ls.exp() * i_n @ t_n.t()
+    loss, acc = O.contrastive_loss(li, li.t())
+    (loss * 2.0).backward()
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=True) for r in range(world)]
+    nloc = N // world
+    dls = sum(o["dls"] for o in outs)                              # SUM over ranks, as allreduce_gradients does
+    for r, o in enumerate(outs):
+        assert abs(o["loss"].item() - loss.item()) < 1e-6          # every rank reports the GLOBAL loss
+        assert abs(o["stats"][1].item() - acc.item() * N) < 1e-6   # global #correct
+        assert torch.allclose(o["dfi"], fi.grad[r * nloc:(r + 1) * nloc], atol=1e-6)
+        assert torch.allclose(o["dft"], ft.grad[r * nloc:(r + 1) * nloc], atol=1e-6)
+        assert o["gsum_ok"]
+    assert abs(dls.item() - ls.grad.item()) < 1e-6
+
+
+def test_single_process_path_of_fused_loss_matches_oracle():
+    sys.path.insert(0, HERE)
+    import clip.loss as closs
+    import cpu_ops_shim
+    old = closs.ops
+    closs.ops = cpu_ops_shim
+    try:
+        from oracle import clip_oracle as O
+        g = torch.Generator().manual_seed(5)
+        fi = torch.randn(9, 8, generator=g).requires_grad_(True)
+        ft = torch.randn(9, 8, generator=g).requires_grad_(True)
+        ls = torch.tensor(2.0, requires_grad=True)
+        loss, stats = closs.contrastive_loss(fi, ft, ls)
+        loss.backward()
+        a, b, c = fi.grad.clone(), ft.grad.clone(), ls.grad.clone()
+        fi.grad = ft.grad = ls.grad = None
+        i_n, t_n = fi / fi.norm(dim=1, keepdim=True), ft / ft.norm(dim=1, keepdim=True)
+        li = ls.exp() * i_n @ t_n.t()
+        ref, acc = O.contrastive_loss(li, li.t())
+        ref.backward()
+        assert abs(loss.item() - ref.item()) < 1e-6 and abs(stats[1].item() - acc.item() * 9) < 1e-6
+        assert torch.allclose(a, fi.grad, atol=1e-6) and torch.allclose(b, ft.grad, atol=1e-6)
+        assert abs(c.item() - ls.grad.item()) < 1e-6
+    finally:
+        closs.ops = old

@@ -1,0 +1,141 @@
+"""CPU: host-side logic of the `clip` drop-in that needs no GPU - state_dict layout, geometry inference,
+tokenizer mechanics, preprocess, schedule/optimizer bookkeeping, and the 'no CPU fallback' rule."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import clip
+from clip.weights import MODELS, init_state_dict, geometry_from_state_dict
+
+
+def test_state_dict_layout_is_openai_clip():
+    geo = MODELS["ViT-B/32"]
+    model = clip.CLIP(geo)
+    sd = model.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 151_277_313
+    assert len(sd) == 302
+    for k, shape in {"visual.conv1.weight": (768, 3, 32, 32), "visual.class_embedding": (768,),
+                     "visual.positional_embedding": (50, 768), "visual.proj": (768, 512),
+                     "visual.transformer.resblocks.11.attn.in_proj_weight": (2304, 768),
+                     "visual.transformer.resblocks.0.attn.out_proj.bias": (768,),
+                     "visual.transformer.resblocks.3.mlp.c_fc.weight": (3072, 768),
+                     "visual.transformer.resblocks.3.mlp.c_proj.weight": (768, 3072),
+                     "token_embedding.weight": (49408, 512), "positional_embedding": (77, 512),
+                     "transformer.resblocks.11.ln_2.bias": (512,), "ln_final.weight": (512,),
+                     "text_projection": (512, 512), "logit_scale": ()}.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert set(sd) == set(init_state_dict(geo, 1))
+
+
+def test_build_model_infers_geometry_and_roundtrips(tmp_path):
+    for name in ("test-tiny", "test-small"):
+        sd = init_state_dict(MODELS[name], 3)
+        assert geometry_from_state_dict(sd) == MODELS[name]
+        m = clip.build_model({k: v.half() for k, v in sd.items()})       # fp16 checkpoints (reference CUDA) load too
+        assert m.dtype == torch.float32
+        path = tmp_path / "ck.pt"
+        torch.save(m.state_dict(), path)                                  # CLIP/train.py:213-217
+        m2, pre = clip.load(str(path), device="cpu")
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, m2.state_dict()[k])
+
+
+def test_no_cpu_fallback():
+    m = clip.build_model(init_state_dict(MODELS["test-tiny"], 3))
+    with pytest.raises(RuntimeError, match="HIP"):
+        m.encode_image(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 16, dtype=torch.int32))
+
+
+def test_load_unknown_and_jit():
+    with pytest.raises(RuntimeError, match="not found"):
+        clip.load("RN50-nope", device="cpu")
+    with pytest.raises(RuntimeError, match="jit"):
+        clip.load("ViT-B/32", device="cpu", jit=True)
+    assert "ViT-B/32" in clip.available_models()
+
+
+def _toy_bpe(path):
+    # a tiny merges file in the format of bpe_simple_vocab_16e6.txt.gz (header line + "a b" merges)
+    merges = ["#version: toy", "h e", "l l", "he ll", "hell o</w>", "w o", "r l", "wo rl", "worl d</w>"]
+    with gzip.open(path, "wb") as f:
+        f.write("\n".join(merges).encode("utf-8"))
+
+
+def test_tokenizer_mechanics(tmp_path, monkeypatch):
+    from clip.simple_tokenizer import SimpleTokenizer
+    p = str(tmp_path / "toy.txt.gz")
+    _toy_bpe(p)
+    tok = SimpleTokenizer(p)
+    assert len(tok.encoder) == 512 + 8 + 2
+    ids = tok.encode("Hello  WORLD")
+    assert [tok.decoder[i] for i in ids] == ["hello</w>", "world</w>"]       # lower-cased, whitespace cleaned, merged
+    assert tok.decode(ids) == "hello world "
+    zh = tok.encode("墜落")                                                   # no merges -> 3 byte tokens per character
+    assert len(zh) == 6 and tok.decode(zh).strip() == "墜落"
+    monkeypatch.setenv("CCLIP_BPE_PATH", p)
+    import clip.clip as cc
+    monkeypatch.setattr(cc, "_tokenizer", None)
+    t = clip.tokenize(["hello world", "墜落"], context_length=12)
+    sot, eot = tok.encoder["<|startoftext|>"], tok.encoder["<|endoftext|>"]
+    assert t.dtype == torch.int32 and t.shape == (2, 12)
+    assert t[0, 0] == sot and t[0, 3] == eot and t[0, 4:].sum() == 0
+    assert int(t[1].argmax()) == 7                                            # EOT is the largest id -> pooling index
+    with pytest.raises(RuntimeError, match="too long"):
+        clip.tokenize("墜落墜落墜落墜落", context_length=12)
+    tt = clip.tokenize("墜落墜落墜落墜落", context_length=12, truncate=True)
+    assert tt[0, -1] == eot
+
+
+def test_tokenize_without_vocab_explains(monkeypatch, tmp_path):
+    import clip.clip as cc
+    monkeypatch.setattr(cc, "_tokenizer", None)
+    monkeypatch.setenv("CCLIP_BPE_PATH", str(tmp_path / "missing.gz"))
+    with pytest.raises(FileNotFoundError, match="CCLIP_BPE_PATH"):
+        clip.tokenize("x")
+
+
+def test_preprocess_matches_definition():
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    arr = rng.randint(0, 256, (300, 420, 3), dtype=np.uint8)
+    img = Image.fromarray(arr)
+    pre = clip._transform(224)
+    out = pre(img)
+    assert out.shape == (3, 224, 224) and out.dtype == torch.float32
+    # manual: resize shorter side to 224 (bicubic), centre crop, /255, normalise
+    r = img.resize((int(224 * 420 / 300), 224), Image.BICUBIC)
+    left = int(round((r.size[0] - 224) / 2.0))
+    c = np.asarray(r.crop((left, 0, left + 224, 224)).convert("RGB"), dtype=np.float32) / 255.0
+    ref = (c - np.array(pre.MEAN, dtype=np.float32)) / np.array(pre.STD, dtype=np.float32)
+    assert np.allclose(out.numpy(), ref.transpose(2, 0, 1), atol=1e-6)
+    # an already-224 grey image goes through untouched
+    g = Image.fromarray(np.full((224, 224), 128, dtype=np.uint8))
+    o2 = pre(g)
+    assert torch.allclose(o2[0], torch.full((224, 224), (128 / 255 - pre.MEAN[0]) / pre.STD[0]), atol=1e-6)
+
+
+def test_linear_schedule_and_bucket_logic():
+    from clip.optim import LinearWarmupSchedule
+    from oracle.optim_oracle import linear_schedule
+
+    class Dummy:
+        param_groups = [dict(lr=2e-5)]
+    s = LinearWarmupSchedule(Dummy(), 5, 30)
+    for step in range(35):
+        assert abs(Dummy.param_groups[0]["lr"] - 2e-5 * linear_schedule(step, 5, 30)) < 1e-15
+        s.step()
+    from cclip_hip.arena import ParamArena
+    from clip.parallel import grad_buckets
+    m = clip.CLIP(MODELS["test-tiny"]).initialize_parameters(1)
+    ar = ParamArena(m, torch.device("cpu"))
+    assert ar.intact() and ar.total % 64 == 0
+    b = grad_buckets(ar, max_bucket_elems=200_000)
+    assert b[0][0] == 0 and b[-1][1] == ar.total and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+    # parameters are views of one flat buffer: an in-place change of the flat buffer is visible in the module
+    ar.flat.add_(1.0)
+    assert torch.equal(m.logit_scale.detach(), ar.flat[ar.offsets["logit_scale"]].reshape(()))
