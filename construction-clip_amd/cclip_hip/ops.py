@@ -226,9 +226,23 @@ def text_embed(text_i32, emb, pos, x, *, rows: int, L: int) -> None:
                                c_int(emb.shape[0]), _p(x), _stream()), "cclip_text_embed")
 
 
-def embed_scatter_add(text_i32, dx, demb, *, rows: int) -> None:
+def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None, seq_stride: Optional[int] = None,
+                      seq_off: int = 0) -> None:
+    L = rows if L is None else L
+    seq_stride = L if seq_stride is None else seq_stride
     check(lib.cclip_embed_scatter_add(_p(text_i32), _p(dx), c_long(dx.stride(-2)), c_int(rows), c_int(demb.shape[1]),
-                                      c_int(demb.shape[0]), _p(demb), _stream()), "cclip_embed_scatter_add")
+                                      c_int(demb.shape[0]), _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off),
+                                      _stream()), "cclip_embed_scatter_add")
+
+
+def caption_embed(prefix_proj, ids_i32, wte, wpe, x, *, B: int, P: int, Lt: int) -> None:
+    check(lib.cclip_caption_embed(_p(prefix_proj), _p(ids_i32), _p(wte), _p(wpe), c_int(B), c_int(P), c_int(Lt),
+                                  c_int(wte.shape[1]), c_int(wte.shape[0]), _p(x), _stream()), "cclip_caption_embed")
+
+
+def add_positional(emb, wpe, x, *, rows: int, S: int) -> None:
+    check(lib.cclip_add_positional(_p(emb), _p(wpe), c_int(rows), c_int(S), c_int(wpe.shape[1]), _p(x), _stream()),
+          "cclip_add_positional")
 
 
 def colsum_ws_floats(R: int, C: int) -> int:

@@ -77,12 +77,13 @@ class BlockStack:
         self.geo, self.blocks, self.scratch = geo, blocks, scratch
 
     # ------------------------------------------------------------------ forward
-    def alloc_saved(self, B: int, device) -> dict:
+    def alloc_saved(self, B: int, device, T: Optional[int] = None) -> dict:
         """Activation store for one training forward.  The caller writes the stack input (fp32 [B*T, D])
         into saved["xs"][0, 0] and passes that view as `x`."""
-        D, T, H = self.geo.width, self.geo.tokens, self.geo.heads
+        D, H = self.geo.width, self.geo.heads
+        T = T or self.geo.tokens
         M, L = B * T, len(self.blocks)
-        return dict(
+        return dict(T=T,
             bf=torch.empty(L, M, 14 * D, device=device, dtype=torch.bfloat16),   # xn1 | qkv | a | xn2 | h | g
             xs=torch.empty(L, 2, M, D, device=device, dtype=torch.float32),      # x_in, x_mid
             st=torch.empty(L, 4, M, device=device, dtype=torch.float32),         # mean1 rstd1 mean2 rstd2
@@ -90,18 +91,19 @@ class BlockStack:
             out=torch.empty(M, D, device=device, dtype=torch.float32), B=B, key_keep=None)
 
     def forward(self, x: torch.Tensor, B: int, *, saved: Optional[dict] = None,
-                key_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+                key_keep: Optional[torch.Tensor] = None, T: Optional[int] = None) -> torch.Tensor:
         """x: fp32 [B*T, D] residual stream entering block 0; returns the stream leaving the last block.
         saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0]."""
         geo = self.geo
-        D, T, H = geo.width, geo.tokens, geo.heads
+        D, H = geo.width, geo.heads
+        T = T or geo.tokens
         M = B * T
         L = len(self.blocks)
         dev = x.device
         kc = geo.linear_layout
         train = saved is not None
         if train:
-            assert x.data_ptr() == saved["xs"][0, 0].data_ptr()
+            assert x.data_ptr() == saved["xs"][0, 0].data_ptr() and saved["T"] == T
             bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
             saved["key_keep"] = key_keep
         else:
@@ -151,8 +153,8 @@ class BlockStack:
         in place layer by layer and on return hold the gradient w.r.t. the stack input.
         acc[id(grad_tensor)] says whether that grad buffer already holds a gradient to add to."""
         geo = self.geo
-        D, T, H = geo.width, geo.tokens, geo.heads
-        B = saved["B"]
+        D, H = geo.width, geo.heads
+        B, T = saved["B"], saved["T"]
         M = B * T
         dev = dx.device
         kc = geo.linear_layout

@@ -1,0 +1,3 @@
+"""MI355X build of the prefix-caption model classes of /root/reference/CLIP_prefix_caption/train.py."""
+from .model import ClipCaptionModel, ClipCaptionPrefix, GPT2LMHeadModel, MLP, MappingType  # noqa: F401
+from .weights import CaptionGeometry, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch  # noqa: F401

@@ -1,0 +1,470 @@
+"""Prefix-caption model of /root/reference/CLIP_prefix_caption/train.py, rebuilt on the HIP kernels:
+
+  MLP                 train.py:110-123   Linear(512, 768P/2) -> Tanh -> Linear(768P/2, 768P)
+  ClipCaptionModel    train.py:251-283   cat(clip_project(prefix), wte(cat(attribute, tokens))) -> GPT-2 -> logits
+  ClipCaptionPrefix   train.py:286-294   mapper-only training (GPT-2 frozen); the reference's version raises
+                                         (`self.gpt` vs `self.model`) - fixed here, not copied.
+  GPT2LMHeadModel     the piece `transformers` contributes at train.py:275; same state_dict keys, so the
+                      files written by torch.save(model.state_dict()) (train.py:371-381) load unchanged.
+
+Same call surface as the reference (`model(tokens, prefix, attribute, mask)` -> object with `.logits`;
+`model.clip_project(prefix)`; `model.model.transformer.wte(ids)`; `model.model(inputs_embeds=..., attention_mask=...)`),
+plus `caption_loss()` - the fused form of train.py:354-357 that only ever materialises the sliced logits rows.
+
+Modules are parameter holders; arithmetic = cclip_hip launches (BlockStack with Conv1D layout + gelu_new +
+causal & key-padding attention).  fp32 masters in a flat arena, bf16 MFMA operands, fp32 residual stream.
+`TransformerMapper` (--mapping_type transformer, train.py:126-248, non-default) is not built yet.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from enum import Enum
+from types import SimpleNamespace
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from cclip_hip import ops
+from cclip_hip.arena import ParamArena
+from cclip_hip.stack import BlockStack, BlockWeights, Scratch, StackGeometry
+
+from .weights import GPT2_MODELS, CaptionGeometry, init_caption_state_dict
+
+
+class MappingType(Enum):
+    MLP = "mlp"
+    Transformer = "transformer"
+
+
+class _Holder(nn.Module):
+    pass
+
+
+class _Affine(_Holder):       # LayerNorm / Linear / Conv1D parameter pair
+    def __init__(self, w_shape, b_shape):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*w_shape))
+        self.bias = nn.Parameter(torch.zeros(*b_shape))
+
+
+class _Sequential(_Holder):
+    """Key layout of nn.Sequential(Linear, Tanh, Linear): parameters live at .0 and .2"""
+
+    def __init__(self, sizes):
+        super().__init__()
+        for i in range(len(sizes) - 1):
+            self.add_module(str(2 * i), _Affine((sizes[i + 1], sizes[i]), (sizes[i + 1],)))
+
+
+class MLP(_Holder):
+    """train.py:110-123.  Only the default 3-size / Tanh form is on the hot path."""
+
+    def __init__(self, sizes: Tuple[int, ...], bias=True, act=nn.Tanh):
+        super().__init__()
+        if len(sizes) != 3 or not bias or act is not nn.Tanh:
+            raise NotImplementedError("HIP mapper implements the reference's default MLP((in, hidden, out), Tanh)")
+        self.sizes = tuple(sizes)
+        self.model = _Sequential(sizes)
+        self._owner = None        # set by ClipCaptionModel: the arena lives on the top-level module
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._owner is None:
+            raise RuntimeError("MLP must be used as ClipCaptionModel.clip_project")
+        return self._owner()._mapper_only(x)
+
+
+class _Embedding(_Holder):
+    def __init__(self, n, d, owner_ref=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, d))
+
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        """wte(ids): fp32 embedding rows through the gather kernel (test.py:540, application.py:105 call this)."""
+        if not ids.is_cuda:
+            raise RuntimeError("wte: HIP path only (no CPU fallback)")
+        flat = ids.reshape(-1).to(torch.int32).contiguous()
+        out = torch.empty(flat.numel(), self.weight.shape[1], device=ids.device, dtype=torch.float32)
+        ops.text_embed(flat, self.weight.data, None, out, rows=flat.numel(), L=flat.numel())
+        return out.view(*ids.shape, -1)
+
+
+class _GPT2Attention(_Holder):
+    def __init__(self, d):
+        super().__init__()
+        self.c_attn = _Affine((d, 3 * d), (3 * d,))      # Conv1D: [in, out]
+        self.c_proj = _Affine((d, d), (d,))
+
+
+class _GPT2MLP(_Holder):
+    def __init__(self, d):
+        super().__init__()
+        self.c_fc = _Affine((d, 4 * d), (4 * d,))
+        self.c_proj = _Affine((4 * d, d), (d,))
+
+
+class _GPT2Block(_Holder):
+    def __init__(self, d):
+        super().__init__()
+        self.ln_1 = _Affine((d,), (d,))
+        self.attn = _GPT2Attention(d)
+        self.ln_2 = _Affine((d,), (d,))
+        self.mlp = _GPT2MLP(d)
+
+
+class _GPT2Transformer(_Holder):
+    def __init__(self, geo: CaptionGeometry):
+        super().__init__()
+        self.wte = _Embedding(geo.vocab_size, geo.n_embd)
+        self.wpe = _Embedding(geo.n_positions, geo.n_embd)
+        self.h = nn.ModuleList([_GPT2Block(geo.n_embd) for _ in range(geo.n_layer)])
+        self.ln_f = _Affine((geo.n_embd,), (geo.n_embd,))
+
+
+class _LMHead(_Holder):
+    def __init__(self, wte: _Embedding):
+        super().__init__()
+        self.weight = wte.weight          # tied, as GPT2LMHeadModel ties lm_head to wte
+
+
+class GPT2LMHeadModel(_Holder):
+    def __init__(self, geo: CaptionGeometry):
+        super().__init__()
+        self.config = SimpleNamespace(vocab_size=geo.vocab_size, n_embd=geo.n_embd, n_layer=geo.n_layer, n_head=geo.n_head,
+                                      n_positions=geo.n_positions)
+        self.geo = geo
+        self.transformer = _GPT2Transformer(geo)
+        self.lm_head = _LMHead(self.transformer.wte)
+        self._owner = None
+
+    @classmethod
+    def from_pretrained(cls, name: str, **kw) -> "GPT2LMHeadModel":
+        """The reference fetches weights here (train.py:275).  Offline: `name` may be a directory / file holding a
+        state_dict (`pytorch_model.bin`, read with weights_only=True); a known name without local files gets seeded
+        synthetic weights and a warning."""
+        geo = GPT2_MODELS.get(name, GPT2_MODELS["ckiplab/gpt2-base-chinese"])
+        m = cls(geo)
+        path = name if os.path.isfile(name) else os.path.join(name, "pytorch_model.bin")
+        if os.path.isfile(path):
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+            sd = {k: v for k, v in sd.items() if not k.endswith((".attn.bias", ".attn.masked_bias"))}
+            sd.setdefault("lm_head.weight", sd["transformer.wte.weight"])
+            m.load_state_dict(sd)
+        else:
+            warnings.warn(f"GPT2LMHeadModel.from_pretrained({name!r}): no local weights and no network - seeded synthetic init")
+            full = init_caption_state_dict(geo, 567)
+            m.load_state_dict({k[len("model."):]: v for k, v in full.items() if k.startswith("model.")})
+        return m
+
+    def forward(self, inputs_embeds=None, attention_mask=None, labels=None, input_ids=None, **kw):
+        if self._owner is None:
+            raise RuntimeError("GPT2LMHeadModel must be used as ClipCaptionModel.model")
+        if labels is not None:
+            raise NotImplementedError("labels= is never used by the reference's live code path (train.py:354 passes None)")
+        if inputs_embeds is None:
+            inputs_embeds = self.transformer.wte(input_ids)
+        return SimpleNamespace(logits=self._owner()._logits_from_embeds(inputs_embeds, attention_mask))
+
+
+_GPT_KEYS = {"ln1_w": "ln_1.weight", "ln1_b": "ln_1.bias", "w_qkv": "attn.c_attn.weight", "b_qkv": "attn.c_attn.bias",
+             "w_o": "attn.c_proj.weight", "b_o": "attn.c_proj.bias", "ln2_w": "ln_2.weight", "ln2_b": "ln_2.bias",
+             "w_fc": "mlp.c_fc.weight", "b_fc": "mlp.c_fc.bias", "w_proj": "mlp.c_proj.weight", "b_proj": "mlp.c_proj.bias"}
+_MATS = ("w_qkv", "w_o", "w_fc", "w_proj")
+
+
+class ClipCaptionModel(nn.Module):
+    def __init__(self, prefix_length: int, clip_length: Optional[int] = None, prefix_size: int = 512, num_layers: int = 8,
+                 mapping_type: MappingType = MappingType.MLP, gpt2_type: str = ""):
+        super().__init__()
+        import weakref
+        self.prefix_length = prefix_length
+        self.model = GPT2LMHeadModel.from_pretrained(gpt2_type) if isinstance(gpt2_type, str) else GPT2LMHeadModel(gpt2_type)
+        self.model_embedding_size = self.model.transformer.wte.weight.shape[1]
+        if mapping_type != MappingType.MLP:
+            raise NotImplementedError("mapping_type=transformer (train.py:126-248) is not built yet; the reference's default is mlp")
+        d = self.model_embedding_size
+        self.clip_project = MLP((prefix_size, (d * prefix_length) // 2, d * prefix_length))
+        ref = weakref.ref(self)
+        self.model._owner = ref
+        self.clip_project._owner = ref
+        self._arena: Optional[ParamArena] = None
+        self._stack: Optional[BlockStack] = None
+
+    @property
+    def gpt(self):            # test.py / application.py name the same submodule `gpt`
+        return self.model
+
+    def get_dummy_token(self, batch_size: int, device) -> torch.Tensor:
+        return torch.zeros(batch_size, self.prefix_length, dtype=torch.int64, device=device)
+
+    def initialize_parameters(self, seed: int = 567):
+        geo = self.model.geo
+        geo = CaptionGeometry(vocab_size=geo.vocab_size, n_embd=geo.n_embd, n_layer=geo.n_layer, n_head=geo.n_head,
+                              n_positions=geo.n_positions, prefix_length=self.prefix_length, attribute_length=0,
+                              prefix_size=self.clip_project.sizes[0])
+        self.load_state_dict(init_caption_state_dict(geo, seed))
+        return self
+
+    # ---- runtime ----
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._arena = self._stack = None
+        return out
+
+    @property
+    def arena(self) -> ParamArena:
+        self._ensure_runtime()
+        return self._arena
+
+    def _ensure_runtime(self):
+        dev = self.model.transformer.wte.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError(f"ClipCaptionModel parameters are on {dev}: the HIP kernels are the only compute path")
+        if self._arena is not None and self._arena.intact():
+            return
+        ar = ParamArena(self, dev)
+        g = self.model.geo
+        blocks = []
+        for i in range(g.n_layer):
+            kw, grads = {}, {}
+            for f, key in _GPT_KEYS.items():
+                name = f"model.transformer.h.{i}.{key}"
+                kw[f] = ar.b[name] if f in _MATS else ar.params[name].data
+                grads[f] = ar.g[name] if ar.params[name].requires_grad else None
+            blocks.append(BlockWeights(grads=grads if all(v is not None for v in grads.values()) else None, **kw))
+        self._arena = ar
+        self._stack = BlockStack(StackGeometry(g.n_embd, g.n_head, 0, False, ops.ACT_GELU_NEW, True), blocks, Scratch(dev))
+
+    # ---- mapper ----
+    def _mapper_forward(self, prefix: torch.Tensor, train: bool):
+        ar = self._arena
+        B = prefix.shape[0]
+        dev = prefix.device
+        n_in, n_hid, n_out = self.clip_project.sizes
+        pb = torch.empty(B, n_in, device=dev, dtype=torch.bfloat16)
+        ops.cast_f32_to_bf16(prefix.detach().float().contiguous(), pb)
+        h1 = torch.empty(B, n_hid, device=dev, dtype=torch.bfloat16)
+        ops.gemm_bf16(pb, ar.b["clip_project.model.0.weight"], bias=ar.params["clip_project.model.0.bias"].data,
+                      act=ops.ACT_TANH, out_bf16=h1)
+        out = torch.empty(B, n_out, device=dev, dtype=torch.float32)
+        ops.gemm_bf16(h1, ar.b["clip_project.model.2.weight"], bias=ar.params["clip_project.model.2.bias"].data, out_f32=out)
+        return out, (pb, h1) if train else None
+
+    def _mapper_only(self, prefix: torch.Tensor) -> torch.Tensor:
+        """`model.clip_project(prefix)` as the inference scripts call it (test.py:540, application.py:104)."""
+        self._ensure_runtime()
+        self._arena.refresh_shadows()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.clip_project.parameters()):
+            raise NotImplementedError("differentiate through ClipCaptionModel.forward / caption_loss, not clip_project alone")
+        return self._mapper_forward(prefix, False)[0]
+
+    # ---- shared forward to the final hidden states ----
+    def _hidden_forward(self, x: torch.Tensor, B: int, S: int, mask: Optional[torch.Tensor], saved: Optional[dict]):
+        keep = None
+        if mask is not None:
+            keep = mask.detach().to(torch.float32).contiguous()
+            assert keep.shape == (B, S), f"attention_mask {tuple(mask.shape)} vs sequence {(B, S)}"
+        return self._stack.forward(x, B, saved=saved, key_keep=keep, T=S)
+
+    def _lm_rows(self, xo: torch.Tensor, rows: torch.Tensor, train: bool):
+        """ln_f on the selected rows + lm_head (tied wte): logits fp32 [len(rows), V]."""
+        ar = self._arena
+        p = ar.params
+        R, D = rows.numel(), self.model_embedding_size
+        dev = xo.device
+        xf = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
+        st = torch.empty(2, R, device=dev, dtype=torch.float32)
+        ops.layernorm_fwd(xo, p["model.transformer.ln_f.weight"].data, p["model.transformer.ln_f.bias"].data, rows=R,
+                          row_index=rows, out_bf16=xf, mean=st[0], rstd=st[1])
+        V = self.model.geo.vocab_size
+        logits = torch.empty(R, (V + 7) // 8 * 8, device=dev, dtype=torch.float32)[:, :V]     # row stride padded to 8
+        ops.gemm_bf16(xf, ar.b["model.transformer.wte.weight"], out_f32=logits)
+        return logits, (xf, st) if train else None
+
+    def _logits_from_embeds(self, inputs_embeds: torch.Tensor, attention_mask) -> torch.Tensor:
+        """GPT2LMHeadModel(inputs_embeds=..., attention_mask=...).logits, inference only (generate loops, test.py:381)."""
+        if torch.is_grad_enabled() and inputs_embeds.requires_grad:
+            raise NotImplementedError("train through ClipCaptionModel.forward / caption_loss")
+        self._ensure_runtime()
+        self._arena.refresh_shadows()
+        B, S, D = inputs_embeds.shape
+        x = torch.empty(B * S, D, device=inputs_embeds.device, dtype=torch.float32)
+        ops.add_positional(inputs_embeds.detach().float().contiguous().view(B * S, D),
+                           self._arena.params["model.transformer.wpe.weight"].data, x, rows=B * S, S=S)
+        xo = self._hidden_forward(x, B, S, attention_mask, None)
+        rows = torch.arange(B * S, device=x.device, dtype=torch.int32)
+        return self._lm_rows(xo, rows, False)[0].unflatten(0, (B, S))
+
+    def _embed_and_run(self, tokens, prefix, attribute, mask, train: bool):
+        self._ensure_runtime()
+        ar = self._arena
+        ar.refresh_shadows()
+        dev = tokens.device
+        B, P, D = tokens.shape[0], self.prefix_length, self.model_embedding_size
+        ids = torch.cat((attribute, tokens), dim=1).to(torch.int32).contiguous()       # train.py:257
+        Lt = ids.shape[1]
+        S = P + Lt
+        proj, msave = self._mapper_forward(prefix, train)                              # train.py:262
+        saved = self._stack.alloc_saved(B, dev, T=S) if train else None
+        x = saved["xs"][0, 0] if train else torch.empty(B * S, D, device=dev, dtype=torch.float32)
+        p = ar.params
+        ops.caption_embed(proj, ids, p["model.transformer.wte.weight"].data, p["model.transformer.wpe.weight"].data, x,
+                          B=B, P=P, Lt=Lt)
+        xo = self._hidden_forward(x, B, S, mask, saved)
+        return xo, dict(saved=saved, msave=msave, ids=ids, B=B, S=S, Lt=Lt, xo=xo)
+
+    # ---- public: reference call signature ----
+    def forward(self, tokens: torch.Tensor, prefix: torch.Tensor, attribute: torch.Tensor,
+                mask: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
+        """train.py:256-269.  Returns an object with `.logits` [B, P+A+L, V] (fp32)."""
+        if labels is not None:
+            raise NotImplementedError("labels= is dead code in the reference (train.py:354 never passes it)")
+        if not tokens.is_cuda:
+            raise RuntimeError("ClipCaptionModel: HIP path only (no CPU fallback)")
+        B, S = tokens.shape[0], self.prefix_length + attribute.shape[1] + tokens.shape[1]
+        rows = torch.arange(B * S, device=tokens.device, dtype=torch.int32)
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            self._ensure_runtime()
+            logits = _CaptionLogits.apply(self, tokens, prefix, attribute, mask, rows, *self._arena.params.values())
+        else:
+            xo, _ = self._embed_and_run(tokens, prefix, attribute, mask, False)
+            logits = self._lm_rows(xo, rows, False)[0]
+        return SimpleNamespace(logits=logits.reshape(B, S, -1) if logits.stride(0) == logits.shape[1] else logits.unflatten(0, (B, S)))
+
+    def caption_loss(self, tokens, prefix, attribute, mask=None, attribute_length: Optional[int] = None):
+        """Fused train.py:354-357: logits[:, P+A-1:-1] vs tokens, CE(ignore_index=0, mean over kept targets).
+        Only the B*L needed rows go through ln_f / lm_head / softmax."""
+        self._ensure_runtime()
+        return _CaptionLoss.apply(self, tokens, prefix, attribute, mask, *self._arena.params.values())
+
+    # ---- backward shared by both autograd nodes ----
+    def _backward_from_dlogits(self, c: dict, dlog_b: torch.Tensor, rows: torch.Tensor, lm):
+        """dlog_b: bf16 [R, V] gradient of the selected logits rows."""
+        ar, stack = self._arena, self._stack
+        p, g = ar.params, ar.g
+        acc = ar.begin_backward()
+        B, S, Lt, P, D = c["B"], c["S"], c["Lt"], self.prefix_length, self.model_embedding_size
+        M = B * S
+        dev = dlog_b.device
+        xf, st = lm
+        R = rows.numel()
+        sc = stack.scratch
+        frozen = not p["model.transformer.wte.weight"].requires_grad
+
+        def A(name):
+            return acc[id(g[name])]
+
+        wte_name = "model.transformer.wte.weight"
+        wrote_wte = False
+        if not frozen:
+            # tied lm_head: gwte (+)= dlogits^T xf      [V, D]
+            n_out, k_in = g[wte_name].shape
+            from cclip_hip.stack import wgrad_splits
+            splits = wgrad_splits(n_out, k_in, R)
+            ops.gemm_bf16(dlog_b, xf, a_kcontig=False, b_kcontig=False, residual=g[wte_name] if A(wte_name) else None,
+                          out_f32=g[wte_name], split_k=splits, split_ws=sc.floats(splits * n_out * k_in) if splits > 1 else None)
+            wrote_wte = True
+        dxf = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
+        ops.gemm_bf16(dlog_b, ar.b[wte_name], b_kcontig=False, out_bf16=dxf)           # dlogits @ wte
+        dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
+        dxb = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+        lnf_w, lnf_b = "model.transformer.ln_f.weight", "model.transformer.ln_f.bias"
+        ops.layernorm_bwd(dxf, c["xo"], p[lnf_w].data, st[0], st[1], rows=R, row_index=rows, dx_out=dx, dx_out_bf16=dxb,
+                          dgamma=None if frozen else g[lnf_w], dbeta=None if frozen else g[lnf_b],
+                          accumulate=False if frozen else A(lnf_w),
+                          ws=None if frozen else sc.floats(ops.layernorm_bwd_ws_floats(R, D)))
+        stack.backward(dx, dxb, c["saved"], acc)
+        if not frozen:
+            # x = [prefix_proj | wte[ids]] + wpe[s]
+            wpe = "model.transformer.wpe.weight"
+            if not A(wpe):
+                g[wpe].zero_()
+            ops.colsum(dx, g[wpe][:S].view(-1), sc.floats(ops.colsum_ws_floats(B, S * D)), R=B, C=S * D, ld=S * D, accumulate=True)
+            ops.embed_scatter_add(c["ids"].view(-1), dx, g[wte_name], rows=B * Lt, L=Lt, seq_stride=S, seq_off=P)
+        # mapper: d prefix_proj = dx[b, :P]  -> a [B, P*D] matrix with row stride S*D inside dx / dxb
+        if p["clip_project.model.2.weight"].requires_grad:
+            pb, h1 = c["msave"]
+            n_in, n_hid, n_out = self.clip_project.sizes
+            dproj = dxb.view(B, S * D)[:, :P * D]
+            w0, b0, w2, b2 = ("clip_project.model.0.weight", "clip_project.model.0.bias", "clip_project.model.2.weight",
+                              "clip_project.model.2.bias")
+            ops.gemm_bf16(dproj, h1, a_kcontig=False, b_kcontig=False, residual=g[w2] if A(w2) else None, out_f32=g[w2])
+            ops.colsum(dproj, g[b2], sc.floats(ops.colsum_ws_floats(B, n_out)), R=B, C=n_out, ld=S * D, accumulate=A(b2))
+            dh1 = torch.empty(B, n_hid, device=dev, dtype=torch.bfloat16)
+            ops.gemm_bf16(dproj, ar.b[w2], b_kcontig=False, act=ops.ACT_DTANH, aux=h1, out_bf16=dh1)
+            ops.gemm_bf16(dh1, pb, a_kcontig=False, b_kcontig=False, residual=g[w0] if A(w0) else None, out_f32=g[w0])
+            ops.colsum(dh1, g[b0], sc.floats(ops.colsum_ws_floats(B, n_hid)), R=B, C=n_hid, ld=n_hid, accumulate=A(b0))
+        ar.publish_grads([n for n in ar.names if ar.params[n].requires_grad])
+
+
+class ClipCaptionPrefix(ClipCaptionModel):
+    """Mapper-only training (train.py:286-294): GPT-2 frozen."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        for q in self.model.parameters():
+            q.requires_grad_(False)
+
+    def parameters(self, recurse: bool = True):
+        return self.clip_project.parameters()
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        self.model.eval()
+        return self
+
+
+class _CaptionLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: ClipCaptionModel, tokens, prefix, attribute, mask, rows, *params):
+        xo, c = model._embed_and_run(tokens, prefix, attribute, mask, True)
+        logits, lm = model._lm_rows(xo, rows, True)
+        ctx.model, ctx.c, ctx.lm, ctx.rows, ctx.n = model, c, lm, rows, len(params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        R, V = dlogits.shape
+        Vp = (V + 7) // 8 * 8
+        d = torch.zeros(R, Vp, device=dlogits.device, dtype=torch.float32)
+        d[:, :V].copy_(dlogits)                                             # re-stride onto the 8-padded layout (plumbing)
+        db = torch.empty(R, Vp, device=d.device, dtype=torch.bfloat16)
+        ops.cast_f32_to_bf16(d, db)
+        ctx.model._backward_from_dlogits(ctx.c, db[:, :V], ctx.rows, ctx.lm)
+        ctx.c = ctx.lm = None
+        return (None,) * (6 + ctx.n)
+
+
+class _CaptionLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: ClipCaptionModel, tokens, prefix, attribute, mask, *params):
+        need_grad = any(ctx.needs_input_grad)
+        xo, c = model._embed_and_run(tokens, prefix, attribute, mask, need_grad)
+        B, S, Lc = c["B"], c["S"], tokens.shape[1]
+        dev = tokens.device
+        first = S - Lc - 1                                                    # = P + A - 1 (train.py:356)
+        rows = (torch.arange(B, device=dev)[:, None] * S + first + torch.arange(Lc, device=dev)[None, :]).reshape(-1).to(torch.int32)
+        logits, lm = model._lm_rows(xo, rows, need_grad)
+        labels = tokens.reshape(-1).to(torch.int32).contiguous()
+        kept = int((labels != 0).sum().item())                               # mean over non-ignored targets
+        R = rows.numel()
+        loss_rows = torch.empty(R, device=dev, dtype=torch.float32)
+        V = logits.shape[1]
+        dlog = torch.zeros(R, (V + 7) // 8 * 8, device=dev, dtype=torch.bfloat16)[:, :V] if need_grad else None   # finite pads
+        ops.xent_rows(logits, labels, loss_row=loss_rows, dlogits=dlog, grad_scale=1.0 / max(kept, 1), ignore_index=0)
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+        ops.reduce_dot(loss_rows, None, out, alpha=1.0 / max(kept, 1))
+        if need_grad:
+            ctx.model, ctx.c, ctx.lm, ctx.rows, ctx.dlog, ctx.n = model, c, lm, rows, dlog, len(params)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        # dlogits were formed for dloss = 1; a different upstream scalar would need a rescale of the bf16 rows
+        if float(dloss) != 1.0:
+            raise NotImplementedError("caption_loss() must be the root of backward (loss.backward(), as train.py:358 does); "
+                                      "for a scaled loss use ClipCaptionModel.forward + torch cross_entropy")
+        ctx.model._backward_from_dlogits(ctx.c, ctx.dlog, ctx.rows, ctx.lm)
+        ctx.c = ctx.lm = ctx.dlog = None
+        return (None,) * (5 + ctx.n)

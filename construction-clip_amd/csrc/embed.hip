@@ -115,13 +115,51 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__
   }
 }
 
+// ids are [n_seq, L]; the gradient row of id (b, j) is dx row b*seq_stride + seq_off + j
 __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int* __restrict__ text, const float* __restrict__ dx,
-                                                                long lddx, int rows, int D, int V, float* __restrict__ demb) {
+                                                                long lddx, int rows, int D, int V, float* __restrict__ demb,
+                                                                int L, int seq_stride, int seq_off) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
     int tok = text[r];
     tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-    for (int col = lane; col < D; col += 64) atomicAdd(demb + (long)tok * D + col, dx[(long)r * lddx + col]);
+    const long src = (long)(r / L) * seq_stride + seq_off + (r % L);
+    for (int col = lane; col < D; col += 64) atomicAdd(demb + (long)tok * D + col, dx[src * lddx + col]);
+  }
+}
+
+// GPT-2 input rows for the prefix-caption model (CLIP_prefix_caption/train.py:258-263):
+//   x[b, s] = (s < P ? prefix_proj[b, s] : wte[ids[b, s - P]]) + wpe[s]
+__global__ __launch_bounds__(256) void caption_embed_kernel(const float* __restrict__ prefix_proj, const int* __restrict__ ids,
+                                                            const float* __restrict__ wte, const float* __restrict__ wpe,
+                                                            int B, int P, int Lt, int D, int V, float* __restrict__ x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = P + Lt, rows = B * S;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const int b = r / S, s = r % S;
+    const float* src;
+    if (s < P) src = prefix_proj + ((long)b * P + s) * D;
+    else {
+      int tok = ids[b * Lt + (s - P)];
+      tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+      src = wte + (long)tok * D;
+    }
+    for (int col = lane * 4; col < D; col += 256) {
+      const float4 e = *(const float4*)(src + col), p = *(const float4*)(wpe + (long)s * D + col);
+      *(float4*)(x + (long)r * D + col) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
+  }
+}
+// x = inputs_embeds + wpe[s]   (GPT2LMHeadModel(inputs_embeds=...), the generate loops' entry)
+__global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ emb, const float* __restrict__ wpe, int rows,
+                                                      int S, int D, float* __restrict__ x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const int s = r % S;
+    for (int col = lane * 4; col < D; col += 256) {
+      const float4 e = *(const float4*)(emb + (long)r * D + col), p = *(const float4*)(wpe + (long)s * D + col);
+      *(float4*)(x + (long)r * D + col) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
   }
 }
 
@@ -219,9 +257,27 @@ extern "C" int cclip_text_embed(const int32_t* text, const float* emb, const flo
 }
 
 extern "C" int cclip_embed_scatter_add(const int32_t* text, const float* dx, int64_t lddx, int32_t rows, int32_t D,
-                                       int32_t V, float* demb, hipStream_t stream) {
-  if (!text || !dx || !demb || rows <= 0 || D <= 0 || V <= 0) return CCLIP_ERR_ARG;
-  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, text, dx, (long)lddx, rows, D, V, demb);
+                                       int32_t V, float* demb, int32_t L, int32_t seq_stride, int32_t seq_off,
+                                       hipStream_t stream) {
+  if (!text || !dx || !demb || rows <= 0 || D <= 0 || V <= 0 || L <= 0) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, text, dx, (long)lddx, rows, D, V,
+                     demb, L, seq_stride, seq_off);
+  return cclip_launch_status();
+}
+
+extern "C" int cclip_caption_embed(const float* prefix_proj, const int32_t* ids, const float* wte, const float* wpe,
+                                   int32_t B, int32_t P, int32_t Lt, int32_t D, int32_t V, float* x, hipStream_t stream) {
+  if (!wte || !wpe || !x || B <= 0 || P < 0 || Lt < 0 || P + Lt <= 0 || (D & 3) || V <= 0) return CCLIP_ERR_ARG;
+  if ((P > 0 && !prefix_proj) || (Lt > 0 && !ids)) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(caption_embed_kernel, dim3(grid_rows4(B * (P + Lt))), dim3(256), 0, stream, prefix_proj, ids, wte, wpe, B,
+                     P, Lt, D, V, x);
+  return cclip_launch_status();
+}
+
+extern "C" int cclip_add_positional(const float* emb, const float* wpe, int32_t rows, int32_t S, int32_t D, float* x,
+                                    hipStream_t stream) {
+  if (!emb || !wpe || !x || rows <= 0 || S <= 0 || (D & 3)) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(add_pos_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, emb, wpe, rows, S, D, x);
   return cclip_launch_status();
 }
 

@@ -84,7 +84,8 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, long ld, 
     } else {
       const int kr = rb * 4 + (lane >> 4);                  // k-row 0..63
       const int c = (lane & 15) ^ fswz(kr);
-      int gc = r0 + c * 8; gc = gc <= R - 8 ? gc : R - 8;
+      const int rpad = ((R + 7) & ~7) - 8;                  // last 16-B chunk of the (8-padded) row
+      int gc = r0 + c * 8; gc = gc <= rpad ? gc : rpad;
       const int gk = k0 + kr;
       src = G + (long)gk * ld + gc;
       if (gk >= Kend) src = (const bf16*)g_zero16;          // ragged contraction edge contributes zeros
@@ -206,50 +207,84 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
       if (p.split_ws) {
         float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
         *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         continue;
       }
+      const bool full = n0 + 8 <= p.N;          // N need not be a multiple of 8: the last run is handled per element
       if (p.alpha != 1.0f) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
       }
       if (p.bias) {
-        const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        if (full) {
+          const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += p.bias[n0 + r];
+        }
       }
       if (p.out_pre) {
-        bf16x8 o;
+        bf16* o = p.out_pre + (long)m * p.ldc + n0;
+        if (full) {
+          bf16x8 t;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
-        *(bf16x8*)(p.out_pre + (long)m * p.ldc + n0) = o;
+          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+          *(bf16x8*)o = t;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+        }
       }
       if (ACT != CCLIP_ACT_NONE) {
         float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ACT >= CCLIP_ACT_DQUICKGELU) {
-          const bf16x8 ax = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n0);
+          const bf16* ap = p.aux + (long)m * p.ldaux + n0;
+          if (full) {
+            const bf16x8 ax = *(const bf16x8*)ap;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) a[r] = (float)ax[r];
+            for (int r = 0; r < 8; ++r) a[r] = (float)ax[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) a[r] = (float)ap[r];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], a[r]);
       }
       if (p.residual) {
         const float* rp = p.residual + (long)m * p.ldr + n0;
-        const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        if (full) {
+          const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+          v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += rp[r];
+        }
       }
       if (p.out_f32) {
         float* o = p.out_f32 + (long)m * p.ldc + n0;
-        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (full) {
+          *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = v[r];
+        }
       }
       if (p.out_bf16) {
-        bf16x8 o;
+        bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
+        if (full) {
+          bf16x8 t;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
-        *(bf16x8*)(p.out_bf16 + (long)m * p.ldc + n0) = o;
+          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+          *(bf16x8*)o = t;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+        }
       }
     }
   }
@@ -282,9 +317,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 extern "C" int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream) {
   if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return CCLIP_ERR_ARG;
-  if ((d->N & 7) || (d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
-  if ((d->a_kcontig || d->b_kcontig) && (d->K & 7)) return CCLIP_ERR_ARG;   // K-strided operands take any K
-  if (!d->a_kcontig && (d->M & 7)) return CCLIP_ERR_ARG;
+  if ((d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
   if (!d->a_kcontig && d->b_kcontig) return CCLIP_ERR_ARG;   // (0,1) is not a layout this path uses
   if ((uintptr_t)d->A & 15 || (uintptr_t)d->B & 15) return CCLIP_ERR_ARG;
   if (d->residual && (d->ldr & 3)) return CCLIP_ERR_ARG;

@@ -48,8 +48,11 @@ enum {
  * Replaces nn.Linear / nn.MultiheadAttention projections / Conv1D / lm_head matmuls and their
  * dgrad + wgrad.  a_kcontig: A(m,k) at A[m*lda+k] (1) or A[k*lda+m] (0); b_kcontig: B(n,k) at
  * B[n*ldb+k] (1) or B[k*ldb+n] (0).  Supported (a,b): (1,1) forward, (1,0) dgrad / Conv1D,
- * (0,0) wgrad.  Contract: N, lda, ldb, ldc multiples of 8; K multiple of 8 unless both operands are
- * K-strided (wgrad: any token count); M multiple of 8 when a_kcontig=0;
+ * (0,0) wgrad.  Contract: lda, ldb, ldc (and ldr % 4, ldaux % 8) multiples of 8 elements and every row
+ * readable up to the next multiple of 8 columns (pad the leading dimension; e.g. a vocabulary of
+ * 50257 uses ld 50264) - M, N and K themselves are arbitrary; when K is not a multiple of 8 the pad
+ * columns of a K-contiguous operand up to the next multiple of 8 must hold finite values (the other
+ * operand's matching k-rows are zero-filled by the kernel);
  * A and B 16-byte aligned.  Epilogue order: *alpha, +bias[n], (store out_pre_bf16), act,
  * +residual[m][n] (fp32, may alias out_f32), store out_f32 and/or out_bf16.
  * split_k > 1: K is cut into split_k ranges whose fp32 partial tiles go to split_ws
@@ -133,7 +136,11 @@ int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int
  * cclip_vit_embed_ln: x0 = patch_out + positional_embedding[t] (+ class_embedding at t = 0),
  *   x = ln_pre(x0); optional saves x0, mean, rstd.  All fp32 [rows = B*T, D].
  * cclip_text_embed: x[r] = token_embedding[text[r]] + positional_embedding[r % L] (pos may be NULL).
- * cclip_embed_scatter_add: demb[text[r]] += dx[r]   (fp32 atomics).
+ * cclip_embed_scatter_add: ids are [n, L]; demb[text[r]] += dx[(r/L)*seq_stride + seq_off + r%L]  (fp32 atomics;
+ *   text tower: L = seq_stride = 77, seq_off = 0; caption model: the token part of a longer sequence).
+ * cclip_caption_embed: x[b,s] = (s < P ? prefix_proj[b,s] : wte[ids[b,s-P]]) + wpe[s] - the
+ *   `cat(clip_project(prefix), wte(cat(attribute,tokens)))` + GPT-2 position add of
+ *   CLIP_prefix_caption/train.py:258-263,268.  cclip_add_positional: x = inputs_embeds + wpe[s].
  * cclip_colsum: out[c] (+)= sum_r in[r*ld + c]; in bf16 (ld % 8 == 0) or fp32 (ld % 4 == 0), 16-byte
  *   aligned; C % 4 == 0; deterministic;
  *   ws >= cclip_colsum_ws_floats(R, C) floats. */
@@ -144,7 +151,12 @@ int cclip_vit_embed_ln(const float* patch_out, const float* cls, const float* po
 int cclip_text_embed(const int32_t* text, const float* emb, const float* pos, int32_t rows, int32_t L,
                      int32_t D, int32_t V, float* x, hipStream_t stream);
 int cclip_embed_scatter_add(const int32_t* text, const float* dx, int64_t lddx, int32_t rows, int32_t D,
-                            int32_t V, float* demb, hipStream_t stream);
+                            int32_t V, float* demb, int32_t L, int32_t seq_stride, int32_t seq_off,
+                            hipStream_t stream);
+int cclip_caption_embed(const float* prefix_proj, const int32_t* ids, const float* wte, const float* wpe,
+                        int32_t B, int32_t P, int32_t Lt, int32_t D, int32_t V, float* x, hipStream_t stream);
+int cclip_add_positional(const float* emb, const float* wpe, int32_t rows, int32_t S, int32_t D, float* x,
+                         hipStream_t stream);
 int cclip_colsum_ws_floats(int32_t R, int32_t C);
 int cclip_colsum(const void* in, int32_t in_is_bf16, int64_t ld, int32_t R, int32_t C, float* out,
                  int32_t accumulate, float* ws, hipStream_t stream);

@@ -1,0 +1,106 @@
+"""GPU parity of the prefix-caption path (mapper MLP + GPT-2 prefix forward/backward + fused LM loss) against the
+CPU oracle's golden vectors.  Tolerances as in test_clip_parity_gpu.py (bf16 operands): logits abs <= 0.05 on a range
+of ~+-1.3, loss <= 5e-3, gradients rel L2 <= 6e-2 (tied wte gets lm_head + embedding contributions)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def sample(t, keep=4096):
+    f = t.detach().flatten()
+    k = max(1, -(-f.numel() // keep))
+    return f[::k].clone()
+
+
+def _setup():
+    from clip_caption import ClipCaptionModel, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch
+    g = torch.load(os.path.join(GOLD, "caption_test_tiny.pt"), weights_only=True)
+    geo = GPT2_MODELS[g["model"]]
+    model = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+    model.load_state_dict(init_caption_state_dict(geo, g["seed"]))
+    model = model.cuda().train()
+    tokens, mask, prefix, attribute = [t.cuda() for t in synthetic_caption_batch(g["b"], geo, g["lc"], g["seed"] + 1)]
+    return g, geo, model, tokens, mask, prefix, attribute
+
+
+def test_caption_forward_logits_and_mapper():
+    g, geo, model, tokens, mask, prefix, attribute = _setup()
+    with torch.no_grad():
+        out = model(tokens, prefix, attribute, mask)
+        mapped = model.clip_project(prefix)
+    P, A = geo.prefix_length, geo.attribute_length
+    assert out.logits.shape == (g["b"], P + A + g["lc"], geo.vocab_size)
+    sl = out.logits[:, P + A - 1:-1]
+    assert (sample(sl, 8192).cpu() - g["logits_slice"]).abs().max() < 0.05
+    assert rel(sample(mapped, 8192), g["mapper_out"]) < 1.2e-2
+    # the generate loops' entry: gpt(inputs_embeds=...) == forward() on the same embeddings
+    with torch.no_grad():
+        emb = torch.cat((mapped.view(-1, P, geo.n_embd), model.gpt.transformer.wte(torch.cat((attribute, tokens), 1))), 1)
+        lg2 = model.gpt(inputs_embeds=emb, attention_mask=mask).logits
+    assert torch.equal(lg2, out.logits)
+
+
+def test_caption_loss_and_grads_fused():
+    g, geo, model, tokens, mask, prefix, attribute = _setup()
+    loss = model.caption_loss(tokens, prefix, attribute, mask)
+    loss.backward()
+    assert abs(loss.item() - g["loss"].item()) < 5e-3
+    params = dict(model.named_parameters())
+    for k, ref in g["grads"].items():
+        assert params[k].grad is not None, k
+        assert rel(sample(params[k].grad), ref) < 6e-2, (k, rel(sample(params[k].grad), ref))
+    for k, nrm in g["grad_norms"].items():
+        if k == "model.lm_head.weight":
+            continue
+        assert abs(params[k].grad.norm().item() - nrm.item()) <= 0.04 * nrm.item() + 1e-7, k
+
+
+def test_caption_reference_loop_with_torch_ce():
+    """train.py:354-361 verbatim: outputs.logits slice -> nnf.cross_entropy(ignore_index=0) -> backward -> optimiser."""
+    g, geo, model, tokens, mask, prefix, attribute = _setup()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    P, A = geo.prefix_length, geo.attribute_length
+    losses = []
+    for _ in range(3):
+        model.zero_grad()
+        outputs = model(tokens, prefix, attribute, mask)
+        logits = outputs.logits[:, P + A - 1:-1]
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tokens.flatten(), ignore_index=0)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    assert abs(losses[0] - g["loss"].item()) < 5e-3 and losses[-1] < losses[0]
+
+
+def test_prefix_only_training_freezes_gpt():
+    from clip_caption import ClipCaptionPrefix, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch
+    geo = GPT2_MODELS["test-tiny"]
+    model = ClipCaptionPrefix(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+    model.load_state_dict(init_caption_state_dict(geo, 3))
+    model = model.cuda().train()
+    tokens, mask, prefix, attribute = [t.cuda() for t in synthetic_caption_batch(2, geo, 10, 4)]
+    model.caption_loss(tokens, prefix, attribute, mask).backward()
+    assert all(p.grad is not None for p in model.clip_project.parameters())
+    assert all(p.grad is None for p in model.model.parameters())
+    assert len(list(model.parameters())) == 4
+
+
+def test_key_padding_mask_is_honoured():
+    g, geo, model, tokens, mask, prefix, attribute = _setup()
+    m2 = mask.clone()
+    m2[:, -3:] = 0
+    with torch.no_grad():
+        a = model(tokens, prefix, attribute, mask).logits
+        b = model(tokens, prefix, attribute, m2).logits
+    assert not torch.equal(a[:, -1], b[:, -1])            # last position no longer sees the masked keys... nor itself
+    assert torch.equal(a[:, : a.shape[1] - 3], b[:, : a.shape[1] - 3])   # causal: earlier positions never saw them

@@ -133,9 +133,32 @@ def test_gemm_wgrad_splitk(splits):
     _report(f"wgrad split{splits}", grad, ref, 2e-3)
 
 
+def test_gemm_unaligned_n_and_k_with_padded_ld():
+    """vocabulary-like shapes: N = 300 / K = 300 (not multiples of 8) on leading dimensions padded to 304."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(77)
+    M, N, K = 130, 300, 128
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    out = torch.full((M, 304), float("nan"), device="cuda")[:, :N]
+    ops.gemm_bf16(A, W, bias=bias, out_f32=out)                      # lm_head: N = 300
+    torch.cuda.synchronize()
+    _report("N=300 fwd", out, A.float() @ W.float().t() + bias, 2e-3)
+    dl = torch.zeros(M, 304, device="cuda", dtype=torch.bfloat16)[:, :N]
+    dl.copy_(torch.randn(M, N, device="cuda", generator=g))
+    dx = torch.empty(M, K, device="cuda")
+    ops.gemm_bf16(dl, W, b_kcontig=False, out_f32=dx)                # dgrad: K = 300
+    gw = torch.empty(N, K, device="cuda")
+    ops.gemm_bf16(dl, A, a_kcontig=False, b_kcontig=False, out_f32=gw)   # wgrad: M' = 300
+    torch.cuda.synchronize()
+    _report("K=300 dgrad", dx, dl.float() @ W.float(), 2e-3)
+    _report("M=300 wgrad", gw, dl.float().t() @ A.float(), 2e-3)
+
+
 def test_gemm_bad_args_raise():
     ops = _ops()
-    A = torch.zeros(64, 60, device="cuda", dtype=torch.bfloat16)   # K not a multiple of 8
+    A = torch.zeros(64, 60, device="cuda", dtype=torch.bfloat16)   # row stride not a multiple of 8
     B = torch.zeros(64, 60, device="cuda", dtype=torch.bfloat16)
     out = torch.zeros(64, 64, device="cuda")
     with pytest.raises(RuntimeError):
