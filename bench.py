@@ -34,18 +34,30 @@ PAIR_FWD_FLOPS = 14_777_163_776          # encode_image 8 817 623 
 PEAK_BF16 = 2.5e15                       # dense bf16 MFMA, MI355X_MICROARCH.md
 
 
-def cpu_baseline(mode: str, budget_s: float = 20.0):
-    """Oracle step on the host cores: bounded sample (batch 16), median of a few iterations."""
-    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
-    from oracle import clip_oracle as O
-    cores = os.cpu_count() or 1
+def host_cores() -> int:
+    """CPU share this process may actually use: min(affinity mask, cgroup quota, 16 = one GPU's share of the box)."""
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = min(n, len(os.sched_getaffinity(0)))
     except Exception:
         pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(mode: str, budget_s: float = 20.0):
+    """Oracle step on the host cores: bounded sample (batch 8), median of a few iterations."""
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    from oracle import clip_oracle as O
+    cores = host_cores()
     torch.set_num_threads(cores)
     geo = MODELS["ViT-B/32"]
-    bs = 16
+    bs = 8
     sd = init_state_dict(geo, 567)
     img, txt = synthetic_images(bs, geo, 568), synthetic_text(bs, geo, 569)
     times = []

@@ -50,7 +50,58 @@ class GemmDesc(ctypes.Structure):
         ("residual", c_void_p), ("ldr", c_long),
         ("out_f32", c_void_p), ("out_bf16", c_void_p), ("out_pre_bf16", c_void_p), ("ldc", c_long),
         ("split_k", c_int), ("split_ws", c_void_p),
+        ("tile_config", c_int),
     ]
+
+
+# Tile-configuration autotuner.  The three GEMM tile configurations (128x128, 256x128, 256x256) win on different
+# shapes (tile-count quantisation over 256 CUs, K length, epilogue weight), and a model issues ~20 distinct GEMM
+# shapes thousands of times: the first call of a new (shape, layout, epilogue, split) key times the candidates on
+# scratch outputs and caches the winner.  AUTOTUNE=False pins configuration 1.
+AUTOTUNE = True
+_TUNED = {}
+_TUNE_MIN_FLOPS = 2.0 * (1 << 29)
+
+
+def _launch_gemm(d) -> None:
+    check(lib.cclip_gemm_bf16(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
+
+
+def _time_desc(d, reps: int = 3) -> float:
+    _launch_gemm(d)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _launch_gemm(d)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _autotune(d, key, outs, candidates):
+    """candidates: list of (tile_config, split_k).  Outputs are redirected to scratch so that in-place residual
+    GEMMs (x += ...) are not applied more than once."""
+    saved = (d.out_f32, d.out_bf16, d.out_pre_bf16, d.tile_config, d.split_k, d.split_ws)
+    # scratch outputs with the SAME row stride as the real ones (outputs are often column slices of a wider slab)
+    tmp = [torch.empty((d.M, d.ldc), device=t.device, dtype=t.dtype) if t is not None else None for t in outs]
+    d.out_f32 = 0 if tmp[0] is None else tmp[0].data_ptr()
+    d.out_bf16 = 0 if tmp[1] is None else tmp[1].data_ptr()
+    d.out_pre_bf16 = 0 if tmp[2] is None else tmp[2].data_ptr()
+    best, best_t = candidates[0], float("inf")
+    ws = None
+    for cfg, sp in candidates:
+        d.tile_config, d.split_k = cfg, sp
+        if sp > 1:
+            need = sp * d.M * d.N
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(need, device=outs[0].device if outs[0] is not None else "cuda", dtype=torch.float32)
+            d.split_ws = ws.data_ptr()
+        t = _time_desc(d)
+        if t < best_t:
+            best, best_t = (cfg, sp), t
+    d.out_f32, d.out_bf16, d.out_pre_bf16, d.tile_config, d.split_k, d.split_ws = saved
+    _TUNED[key] = best
+    return best
 
 
 def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcontig: bool = True,
@@ -58,9 +109,12 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
               aux: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               out_f32: Optional[torch.Tensor] = None, out_bf16: Optional[torch.Tensor] = None,
               out_pre: Optional[torch.Tensor] = None, split_k: int = 1,
-              split_ws: Optional[torch.Tensor] = None, M: Optional[int] = None) -> None:
+              split_ws: Optional[torch.Tensor] = None, M: Optional[int] = None, tile_config: int = 0,
+              split_candidates=None, scratch=None) -> None:
     """C[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see cclip_gemm_bf16 in include/cclip_hip.h.
-    A: [M,K] (a_kcontig) or [K,M]; B: [N,K] (b_kcontig) or [K,N]; 2-D, inner stride 1."""
+    A: [M,K] (a_kcontig) or [K,M]; B: [N,K] (b_kcontig) or [K,N]; 2-D, inner stride 1.
+    split_candidates (wgrad): list of (tile_config, split_k) to autotune over; `scratch(n)` returns an fp32
+    workspace of n floats for the chosen split."""
     _req(A, torch.bfloat16, "A"); _req(B, torch.bfloat16, "B")
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     Mx, K = (A.shape[0], A.shape[1]) if a_kcontig else (A.shape[1], A.shape[0])
@@ -68,7 +122,8 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     if M is None:
         M = Mx
     assert K == Kb, (A.shape, B.shape, a_kcontig, b_kcontig)
-    outs = [t for t in (out_f32, out_bf16, out_pre) if t is not None]
+    outs3 = (out_f32, out_bf16, out_pre)
+    outs = [t for t in outs3 if t is not None]
     assert outs, "no output"
     ldc = outs[0].stride(0)
     for t in outs:
@@ -91,22 +146,36 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     d.ldc = ldc
     d.split_k = split_k
     d.split_ws = 0 if split_ws is None else split_ws.data_ptr()
+    d.tile_config = tile_config
     if bias is not None:
         _req(bias, torch.float32, "bias")
     if residual is not None:
         _req(residual, torch.float32, "residual")
     if out_f32 is not None:
         _req(out_f32, torch.float32, "out_f32")
-    if split_k > 1:
-        assert split_ws is not None and split_ws.numel() >= split_k * M * N and split_ws.dtype == torch.float32
+    if tile_config == 0 and AUTOTUNE and 2.0 * M * N * K >= _TUNE_MIN_FLOPS and (outs[0].is_contiguous() or True):
+        key = (M, N, K, a_kcontig, b_kcontig, act, out_f32 is not None, out_bf16 is not None, out_pre is not None,
+               residual is not None, bias is not None, split_k if split_candidates is None else -1)
+        choice = _TUNED.get(key)
+        if choice is None:
+            cands = split_candidates if split_candidates is not None else [(1, split_k), (3, split_k)]
+            if split_candidates is None and split_k > 1:
+                d.split_ws = split_ws.data_ptr()
+            choice = _autotune(d, key, outs3, cands)
+        d.tile_config, d.split_k = choice
+        if d.split_k > 1 and split_candidates is not None:
+            ws = scratch(d.split_k * M * N)
+            d.split_ws = ws.data_ptr()
+    if d.split_k > 1:
+        assert d.split_ws, "split_k > 1 needs a workspace"
     if GEMM_EVENTS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.cclip_gemm_bf16(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
+        _launch_gemm(d)
         e1.record()
         GEMM_EVENTS.append((e0, e1, 2.0 * M * N * K, (int(a_kcontig), int(b_kcontig)), (M, N, K)))
         return
-    check(lib.cclip_gemm_bf16(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
+    _launch_gemm(d)
 
 
 # --------------------------------------------------------------------------------------------

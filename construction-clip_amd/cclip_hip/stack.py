@@ -59,6 +59,21 @@ def wgrad_splits(n_out: int, k_in: int, tokens: int) -> int:
     return max(1, min(s, nkt // 4 if nkt >= 8 else 1))
 
 
+def wgrad_candidates(n_out: int, k_in: int, tokens: int):
+    """(tile_config, split_k) candidates for the wgrad autotuner: aim the grid at 1x / 2x / 3x the machine's
+    concurrent workgroups (512 for the 128x128 tile, 256 for the 256x256 tile), >= 4 K-tiles per split."""
+    nkt = (tokens + 63) // 64
+    cands = []
+    for cfg, edge, slots in ((1, 128, 512), (3, 256, 256)):
+        tiles = ((n_out + edge - 1) // edge) * ((k_in + edge - 1) // edge)
+        for mult in (1, 2, 3):
+            s = max(1, min(64, (slots * mult) // max(tiles, 1)))
+            s = max(1, min(s, nkt // 4 if nkt >= 8 else 1))
+            if (cfg, s) not in cands:
+                cands.append((cfg, s))
+    return cands
+
+
 class Scratch:
     """Grow-only device scratch shared by the launches of one stream (split-K slabs, LN/colsum partials)."""
 
@@ -138,10 +153,8 @@ class BlockStack:
         """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out]."""
         a, b = (dy, xin) if self.geo.linear_layout else (xin, dy)
         n_out, k_in = gw.shape
-        splits = wgrad_splits(n_out, k_in, M)
-        ws = self.scratch.floats(splits * n_out * k_in) if splits > 1 else None
         ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
-                      split_k=splits, split_ws=ws)
+                      split_candidates=wgrad_candidates(n_out, k_in, M), scratch=self.scratch.floats)
 
     def _bgrad(self, dy: torch.Tensor, gb: torch.Tensor, M: int, acc: bool):
         C = gb.numel()

@@ -360,10 +360,9 @@ class ClipCaptionModel(nn.Module):
         if not frozen:
             # tied lm_head: gwte (+)= dlogits^T xf      [V, D]
             n_out, k_in = g[wte_name].shape
-            from cclip_hip.stack import wgrad_splits
-            splits = wgrad_splits(n_out, k_in, R)
+            from cclip_hip.stack import wgrad_candidates
             ops.gemm_bf16(dlog_b, xf, a_kcontig=False, b_kcontig=False, residual=g[wte_name] if A(wte_name) else None,
-                          out_f32=g[wte_name], split_k=splits, split_ws=sc.floats(splits * n_out * k_in) if splits > 1 else None)
+                          out_f32=g[wte_name], split_candidates=wgrad_candidates(n_out, k_in, R), scratch=sc.floats)
             wrote_wte = True
         dxf = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
         ops.gemm_bf16(dlog_b, ar.b[wte_name], b_kcontig=False, out_bf16=dxf)           # dlogits @ wte

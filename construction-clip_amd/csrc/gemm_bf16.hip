@@ -27,268 +27,12 @@
 // The MFMA is issued "swapped" (weights as the A operand): the accumulator then holds 4
 // consecutive n per lane, and with the n-permutation P() below each lane owns two runs of 8
 // consecutive output columns -> 16-byte stores, bias/residual/aux read as 16/32-byte vectors.
-#include "cclip_common.h"
-#include "../../include/cclip_hip.h"
+#include <stdlib.h>
+#include "gemm_bf16_impl.h"
 
-#define BM 128
-#define BN 128
-#define BK 64
-#define TILE_BYTES (128 * 64 * 2)        // 16 KiB per operand tile
-#define STAGE_BYTES (2 * TILE_BYTES)     // A + B
-#define LDS_BYTES (2 * STAGE_BYTES)      // double buffered = 64 KiB -> 2 blocks / CU
-
-__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0, 0, 0, 0};
-
-struct GemmArgs {
-  const bf16* A; const bf16* B;
-  long lda, ldb;
-  int M, N, K;
-  int ktiles_per_split;
-  float alpha;
-  const float* bias;
-  const float* residual; long ldr;
-  const bf16* aux; long ldaux;
-  float* out_f32; bf16* out_bf16; bf16* out_pre; long ldc;
-  int act;
-  float* split_ws;   // != nullptr: raw fp32 partial tile stores to split_ws[z][M][N]
-};
-
-// n-permutation: position i (0..15) of MFMA n-tile nt (0..3) of a wave's 64-column block maps to
-// local column P = 8*(i>>2) + 32*(nt>>1) + 4*(nt&1) + (i&3).  With the accumulator map
-// (row = 4*(lane>>4) + reg) a lane then holds columns 8g..8g+7 (nt = 0,1) and 32+8g..32+8g+7
-// (nt = 2,3) of its block.
-__device__ __forceinline__ int nperm(int nt, int i) {
-  return 8 * (i >> 2) + 32 * (nt >> 1) + 4 * (nt & 1) + (i & 3);
-}
-__device__ __forceinline__ int fswz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
-
-// ---- staging: one 16 KiB operand tile = 16 wave-instructions of 1 KiB; wave w issues 4 ----
-// PERM: LDS row position rp of a K-contiguous tile holds tile row 64*(rp>>6) + nperm((rp>>4)&3, rp&15)
-// (free at staging time because the DMA source address is per lane), so fragment reads stay natural.
-template <int KC, int PERM>
-__device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, long ld, int R, int Kend, int r0, int k0,
-                                           char* lds_tile, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rb = wave * 4 + i;
-    const bf16* src;
-    if (KC) {
-      const int rp = rb * 8 + (lane >> 3);                  // LDS row position 0..127
-      const int c = (lane & 7) ^ (rp & 7);                  // logical 16-B chunk held at this LDS slot
-      int r = rp;
-      if (PERM) r = (rp & 64) + nperm((rp >> 4) & 3, rp & 15);
-      int gr = r0 + r; gr = gr < R ? gr : R - 1;            // clamp: rows past the edge are never stored
-      const int gk = k0 + c * 8;
-      src = G + (long)gr * ld + gk;
-      if (gk >= Kend) src = (const bf16*)g_zero16;
-    } else {
-      const int kr = rb * 4 + (lane >> 4);                  // k-row 0..63
-      const int c = (lane & 15) ^ fswz(kr);
-      const int rpad = ((R + 7) & ~7) - 8;                  // last 16-B chunk of the (8-padded) row
-      int gc = r0 + c * 8; gc = gc <= rpad ? gc : rpad;
-      const int gk = k0 + kr;
-      src = G + (long)gk * ld + gc;
-      if (gk >= Kend) src = (const bf16*)g_zero16;          // ragged contraction edge contributes zeros
-    }
-    glds16(src, lds_tile + rb * 1024);
-  }
-}
-
-// ---- fragment reads (lane l: index i = l&15 of the 16-wide tile, k-group g = l>>4: k = 32ks+8g+j) ----
-// K-contiguous tile, natural rows row0..row0+15.
-__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
-  const int row = row0 + (lane & 15);
-  const int c = 4 * ks + (lane >> 4);
-  return *(const bf16x8*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
-}
-// K-strided tile; the tile's 16 columns are given as four 4-column pieces: piece p starts at column col_of_piece(p).
-template <int PERM>
-__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int col0, int nt, int ks, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int col = PERM ? col0 + 8 * p + 32 * (nt >> 1) + 4 * (nt & 1) : col0 + 16 * nt + 4 * p;
-  const int chunk = col >> 3, sub = (col & 7) * 2;
-  const int kr0 = 32 * ks + 8 * g + q, kr1 = kr0 + 4;
-  bf16x4 lo = lds_read_tr16(tile + kr0 * 256 + ((chunk ^ fswz(kr0)) << 4) + sub);
-  bf16x4 hi = lds_read_tr16(tile + kr1 * 256 + ((chunk ^ fswz(kr1)) << 4) + sub);
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-template <int ACT>
-__device__ __forceinline__ float act_apply(float v, float a) {
-  switch (ACT) {
-    case CCLIP_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
-    case CCLIP_ACT_TANH: return tanhf(v);
-    case CCLIP_ACT_GELU_NEW: {
-      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-      return 0.5f * v * (1.0f + tanhf(u));
-    }
-    case CCLIP_ACT_RELU: return fmaxf(v, 0.0f);
-    case CCLIP_ACT_DQUICKGELU: {   // v = upstream grad, a = saved pre-activation
-      const float s = 1.0f / (1.0f + __expf(-1.702f * a));
-      return v * s * (1.0f + 1.702f * a * (1.0f - s));
-    }
-    case CCLIP_ACT_DTANH: return v * (1.0f - a * a);   // a = saved tanh output
-    case CCLIP_ACT_DGELU_NEW: {
-      const float u = 0.7978845608028654f * (a + 0.044715f * a * a * a);
-      const float t = tanhf(u);
-      const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * a * a);
-      return v * (0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * du);
-    }
-    case CCLIP_ACT_DRELU: return a > 0.0f ? v : 0.0f;
-    default: return v;
-  }
-}
-
-template <int A_KC, int B_KC, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bm0 = (bid / tiles_n) * BM, bn0 = (bid % tiles_n) * BN;
-  const int nkt = (p.K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * p.ktiles_per_split;
-  const int kt1 = (kt0 + p.ktiles_per_split < nkt) ? kt0 + p.ktiles_per_split : nkt;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (kt0 < kt1) {
-    stage_tile<A_KC, 0>(p.A, p.lda, p.M, p.K, bm0, kt0 * BK, smem, wave, lane);
-    stage_tile<B_KC, 1>(p.B, p.ldb, p.N, p.K, bn0, kt0 * BK, smem + TILE_BYTES, wave, lane);
-  }
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    // every wave's DMA for tile kt has landed (vmcnt(0) is part of __syncthreads while a
-    // global_load_lds is outstanding) and every wave has finished reading the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < kt1) {
-      char* nb = smem + (cur ^ 1) * STAGE_BYTES;
-      stage_tile<A_KC, 0>(p.A, p.lda, p.M, p.K, bm0, (kt + 1) * BK, nb, wave, lane);
-      stage_tile<B_KC, 1>(p.B, p.ldb, p.N, p.K, bn0, (kt + 1) * BK, nb + TILE_BYTES, wave, lane);
-    }
-    const char* At = smem + cur * STAGE_BYTES;
-    const char* Bt = At + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 xf[4], wf[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-        xf[mt] = A_KC ? frag_rows(At, wm0 + 16 * mt, ks, lane) : frag_cols<0>(At, wm0, mt, ks, lane);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        wf[nt] = B_KC ? frag_rows(Bt, wn0 + 16 * nt, ks, lane) : frag_cols<1>(Bt, wn0, nt, ks, lane);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
-  const int li = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = bm0 + wm0 + 16 * mt + li;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n0 = bn0 + wn0 + 32 * h + 8 * g;
-      if (m >= p.M || n0 >= p.N) continue;
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
-      if (p.split_ws) {
-        float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
-        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-        if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        continue;
-      }
-      const bool full = n0 + 8 <= p.N;          // N need not be a multiple of 8: the last run is handled per element
-      if (p.alpha != 1.0f) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
-      }
-      if (p.bias) {
-        if (full) {
-          const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += p.bias[n0 + r];
-        }
-      }
-      if (p.out_pre) {
-        bf16* o = p.out_pre + (long)m * p.ldc + n0;
-        if (full) {
-          bf16x8 t;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-          *(bf16x8*)o = t;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
-        }
-      }
-      if (ACT != CCLIP_ACT_NONE) {
-        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ACT >= CCLIP_ACT_DQUICKGELU) {
-          const bf16* ap = p.aux + (long)m * p.ldaux + n0;
-          if (full) {
-            const bf16x8 ax = *(const bf16x8*)ap;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a[r] = (float)ax[r];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) a[r] = (float)ap[r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], a[r]);
-      }
-      if (p.residual) {
-        const float* rp = p.residual + (long)m * p.ldr + n0;
-        if (full) {
-          const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
-          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-          v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += rp[r];
-        }
-      }
-      if (p.out_f32) {
-        float* o = p.out_f32 + (long)m * p.ldc + n0;
-        if (full) {
-          *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-          *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = v[r];
-        }
-      }
-      if (p.out_bf16) {
-        bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
-        if (full) {
-          bf16x8 t;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-          *(bf16x8*)o = t;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
-        }
-      }
-    }
-  }
-}
+bool cclip_gemm_launch_cfg1(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
+bool cclip_gemm_launch_cfg2(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
+bool cclip_gemm_launch_cfg3(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
@@ -340,34 +84,16 @@ extern "C" int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream) {
   a.out_f32 = d->out_f32; a.out_bf16 = (bf16*)d->out_bf16; a.out_pre = (bf16*)d->out_pre_bf16; a.ldc = d->ldc;
   a.act = d->act; a.split_ws = splits > 1 ? d->split_ws : nullptr;
 
-  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
-  dim3 grid(tiles, splits), block(256);
-  // instantiated (layout, activation) pairs = exactly the ones the hot path issues
-#define LAUNCH(AK, BKC, ACTV) hipLaunchKernelGGL((gemm_bf16_128<AK, BKC, ACTV>), grid, block, 0, stream, a)
+  int cfg = d->tile_config;
+  if (cfg <= 0 || cfg > 3) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);
+  if (cfg < 1 || cfg > 3) cfg = 1;
+  const int bm = cfg == 1 ? 128 : 256, bn = cfg == 3 ? 256 : 128;
+  const int tiles = ((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
+  dim3 grid(tiles, splits);
   const int lay = d->a_kcontig * 2 + d->b_kcontig;   // 3 = fwd, 2 = dgrad/Conv1D, 0 = wgrad
-  bool launched = true;
-  if (lay == 3) {
-    switch (d->act) {
-      case CCLIP_ACT_NONE: LAUNCH(1, 1, CCLIP_ACT_NONE); break;
-      case CCLIP_ACT_QUICKGELU: LAUNCH(1, 1, CCLIP_ACT_QUICKGELU); break;
-      case CCLIP_ACT_TANH: LAUNCH(1, 1, CCLIP_ACT_TANH); break;
-      case CCLIP_ACT_RELU: LAUNCH(1, 1, CCLIP_ACT_RELU); break;
-      case CCLIP_ACT_DGELU_NEW: LAUNCH(1, 1, CCLIP_ACT_DGELU_NEW); break;
-      default: launched = false;
-    }
-  } else if (lay == 2) {
-    switch (d->act) {
-      case CCLIP_ACT_NONE: LAUNCH(1, 0, CCLIP_ACT_NONE); break;
-      case CCLIP_ACT_GELU_NEW: LAUNCH(1, 0, CCLIP_ACT_GELU_NEW); break;
-      case CCLIP_ACT_DQUICKGELU: LAUNCH(1, 0, CCLIP_ACT_DQUICKGELU); break;
-      case CCLIP_ACT_DTANH: LAUNCH(1, 0, CCLIP_ACT_DTANH); break;
-      case CCLIP_ACT_DRELU: LAUNCH(1, 0, CCLIP_ACT_DRELU); break;
-      default: launched = false;
-    }
-  } else {
-    if (d->act == CCLIP_ACT_NONE) LAUNCH(0, 0, CCLIP_ACT_NONE); else launched = false;
-  }
-#undef LAUNCH
+  const bool launched = cfg == 3   ? cclip_gemm_launch_cfg3(lay, d->act, grid, stream, a)
+                        : cfg == 2 ? cclip_gemm_launch_cfg2(lay, d->act, grid, stream, a)
+                                   : cclip_gemm_launch_cfg1(lay, d->act, grid, stream, a);
   if (!launched) return CCLIP_ERR_ARG;
   int st = cclip_launch_status();
   if (st != CCLIP_OK) return st;

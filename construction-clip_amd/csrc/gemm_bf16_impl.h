@@ -1,0 +1,330 @@
+// Implementation template of the bf16 MFMA GEMM (see gemm_bf16.hip for the description); included by the
+// per-configuration translation units gemm_bf16_cfg*.hip so that they compile in parallel.
+#pragma once
+#include "cclip_common.h"
+#include "../../include/cclip_hip.h"
+
+#define BK 64
+#define TILE_BYTES (128 * 64 * 2)        // one 16 KiB sub-tile: 128 rows (or columns) x 64 k
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0, 0, 0, 0};
+
+struct GemmArgs {
+  const bf16* A; const bf16* B;
+  long lda, ldb;
+  int M, N, K;
+  int ktiles_per_split;
+  float alpha;
+  const float* bias;
+  const float* residual; long ldr;
+  const bf16* aux; long ldaux;
+  float* out_f32; bf16* out_bf16; bf16* out_pre; long ldc;
+  int act;
+  float* split_ws;   // != nullptr: raw fp32 partial tile stores to split_ws[z][M][N]
+};
+
+// n-permutation: position i (0..15) of MFMA n-tile nt (0..3) of a wave's 64-column block maps to
+// local column P = 8*(i>>2) + 32*(nt>>1) + 4*(nt&1) + (i&3).  With the accumulator map
+// (row = 4*(lane>>4) + reg) a lane then holds columns 8g..8g+7 (nt = 0,1) and 32+8g..32+8g+7
+// (nt = 2,3) of its block.
+__device__ __forceinline__ int nperm(int nt, int i) {
+  return 8 * (i >> 2) + 32 * (nt >> 1) + 4 * (nt & 1) + (i & 3);
+}
+__device__ __forceinline__ int fswz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
+
+// ---- staging: an operand tile = NSUB sub-tiles of 16 KiB (128 rows/cols x 64 k); one sub-tile = 16
+// wave-instructions of 1 KiB; the NSUB*16 instructions are dealt round-robin to the NW waves ----
+// PERM: LDS row position rp of a K-contiguous sub-tile holds tile row 64*(rp>>6) + nperm((rp>>4)&3, rp&15)
+// (free at staging time because the DMA source address is per lane), so fragment reads stay natural.
+template <int KC, int PERM, int NSUB, int NW>
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, long ld, int R, int Kend, int r0, int k0,
+                                           char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < NSUB * 16 / NW; ++i) {
+    const int idx = wave + NW * i;
+    const int sub = idx >> 4, rb = idx & 15;
+    const bf16* src;
+    if (KC) {
+      const int rp = rb * 8 + (lane >> 3);                  // LDS row position 0..127 inside the sub-tile
+      const int c = (lane & 7) ^ (rp & 7);                  // logical 16-B chunk held at this LDS slot
+      int r = rp;
+      if (PERM) r = (rp & 64) + nperm((rp >> 4) & 3, rp & 15);
+      int gr = r0 + sub * 128 + r; gr = gr < R ? gr : R - 1;   // clamp: rows past the edge are never stored
+      const int gk = k0 + c * 8;
+      src = G + (long)gr * ld + gk;
+      if (gk >= Kend) src = (const bf16*)g_zero16;
+    } else {
+      const int kr = rb * 4 + (lane >> 4);                  // k-row 0..63
+      const int c = (lane & 15) ^ fswz(kr);
+      const int rpad = ((R + 7) & ~7) - 8;                  // last 16-B chunk of the (8-padded) row
+      int gc = r0 + sub * 128 + c * 8; gc = gc <= rpad ? gc : rpad;
+      const int gk = k0 + kr;
+      src = G + (long)gk * ld + gc;
+      if (gk >= Kend) src = (const bf16*)g_zero16;          // ragged contraction edge contributes zeros
+    }
+    glds16(src, lds_tile + sub * TILE_BYTES + rb * 1024);
+  }
+}
+
+// ---- fragment reads (lane l: index i = l&15 of the 16-wide tile, k-group g = l>>4: k = 32ks+8g+j) ----
+// K-contiguous tile, natural rows row0..row0+15.
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 15);
+  const int c = 4 * ks + (lane >> 4);
+  return *(const bf16x8*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+}
+// K-strided tile; the tile's 16 columns are given as four 4-column pieces: piece p starts at column col_of_piece(p).
+template <int PERM>
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int col0, int nt, int ks, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int col = PERM ? col0 + 8 * p + 32 * (nt >> 1) + 4 * (nt & 1) : col0 + 16 * nt + 4 * p;
+  const int chunk = col >> 3, sub = (col & 7) * 2;
+  const int kr0 = 32 * ks + 8 * g + q, kr1 = kr0 + 4;
+  bf16x4 lo = lds_read_tr16(tile + kr0 * 256 + ((chunk ^ fswz(kr0)) << 4) + sub);
+  bf16x4 hi = lds_read_tr16(tile + kr1 * 256 + ((chunk ^ fswz(kr1)) << 4) + sub);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v, float a) {
+  switch (ACT) {
+    case CCLIP_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
+    case CCLIP_ACT_TANH: return tanhf(v);
+    case CCLIP_ACT_GELU_NEW: {
+      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return 0.5f * v * (1.0f + tanhf(u));
+    }
+    case CCLIP_ACT_RELU: return fmaxf(v, 0.0f);
+    case CCLIP_ACT_DQUICKGELU: {   // v = upstream grad, a = saved pre-activation
+      const float s = 1.0f / (1.0f + __expf(-1.702f * a));
+      return v * s * (1.0f + 1.702f * a * (1.0f - s));
+    }
+    case CCLIP_ACT_DTANH: return v * (1.0f - a * a);   // a = saved tanh output
+    case CCLIP_ACT_DGELU_NEW: {
+      const float u = 0.7978845608028654f * (a + 0.044715f * a * a * a);
+      const float t = tanhf(u);
+      const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * a * a);
+      return v * (0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * du);
+    }
+    case CCLIP_ACT_DRELU: return a > 0.0f ? v : 0.0f;
+    default: return v;
+  }
+}
+
+// WM x WN waves, each a (16*MT)x64 output sub-tile: block tile = (16*MT*WM) x (64*WN).  STAGES LDS stages; the DMA
+// for tile kt+STAGES-1 is issued while tile kt is multiplied, with a COUNTED s_waitcnt vmcnt so that the
+// younger stages stay in flight across the barrier (a plain __syncthreads would drain them).
+template <int A_KC, int B_KC, int ACT, int WM, int WN, int STAGES, int MT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN, BM_ = 16 * MT * WM, BN_ = 64 * WN;
+  constexpr int NSA = (BM_ + 127) / 128, NSB = (BN_ + 127) / 128;   // 128-wide sub-tiles per operand
+  constexpr int STAGE_BYTES_ = (NSA + NSB) * TILE_BYTES;
+  constexpr int G = (NSA + NSB) * 16 / NW;                        // DMA instructions per wave per stage
+  constexpr int PD = STAGES - 1;                                  // prefetch distance in K-tiles
+  __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES_];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN_ - 1) / BN_;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bm0 = (bid / tiles_n) * BM_, bn0 = (bid % tiles_n) * BN_;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt1 = (kt0 + p.ktiles_per_split < nkt) ? kt0 + p.ktiles_per_split : nkt;
+  const int wm = wave / WN, wn = wave % WN;
+  const int wm0 = wm * 16 * MT, wn0 = wn * 64;                    // offsets inside the block tile
+  const int a_off = (wm0 >> 7) * TILE_BYTES, a_row = wm0 & 127;   // sub-tile + row/col offset inside it
+  const int b_off = (wn >> 1) * TILE_BYTES, b_row = (wn & 1) * 64;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < PD; ++s) {
+    if (kt0 + s < kt1) {
+      char* sb = smem + s * STAGE_BYTES_;
+      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt0 + s) * BK, sb, wave, lane);
+      stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt0 + s) * BK, sb + NSA * TILE_BYTES, wave, lane);
+    }
+  }
+  int cur = 0;                                                   // stage holding tile kt
+  for (int kt = kt0; kt < kt1; ++kt) {
+    // tile kt has landed for this wave once at most the younger stages' DMAs are outstanding; the barrier then
+    // (a) publishes every wave's part of tile kt and (b) proves every wave is done reading stage cur-1
+    const int ahead = kt1 - 1 - kt;                              // tiles already issued beyond kt: min(ahead, PD-1)
+    if (PD >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+    else if (PD >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + PD < kt1) {
+      int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
+      char* sb = smem + ns * STAGE_BYTES_;
+      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
+      stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
+    }
+    const char* At = smem + cur * STAGE_BYTES_ + a_off;
+    const char* Bt = smem + cur * STAGE_BYTES_ + NSA * TILE_BYTES + b_off;
+    // register double-buffered fragments: the LDS reads of k-step 1 are issued before, and interleaved with,
+    // the MFMAs of k-step 0, so LDS latency is exposed once per K-tile instead of once per 8 MFMAs
+    bf16x8 xf[2][MT], wf[2][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      xf[0][mt] = A_KC ? frag_rows(At, a_row + 16 * mt, 0, lane) : frag_cols<0>(At, a_row, mt, 0, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      wf[0][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 0, lane) : frag_cols<1>(Bt, b_row, nt, 0, lane);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      xf[1][mt] = A_KC ? frag_rows(At, a_row + 16 * mt, 1, lane) : frag_cols<0>(At, a_row, mt, 1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      wf[1][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 1, lane) : frag_cols<1>(Bt, b_row, nt, 1, lane);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], xf[ks][mt], acc[mt][nt], 0, 0, 0);
+    }
+    // schedule: 8 DS reads (k-step 0) up front, then 2 MFMA : 1 DS read while k-step 1's fragments stream in
+    constexpr int RD = (A_KC ? MT : 2 * MT) + (B_KC ? 4 : 8);     // LDS read instructions per k-step
+    constexpr int NM = 4 * MT;                                    // MFMAs per k-step
+    __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / RD > 0 ? NM / RD : 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
+  }
+
+  // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
+  const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = bm0 + wm0 + 16 * mt + li;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n0 = bn0 + wn0 + 32 * h + 8 * g;
+      if (m >= p.M || n0 >= p.N) continue;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
+      if (p.split_ws) {
+        float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        continue;
+      }
+      const bool full = n0 + 8 <= p.N;          // N need not be a multiple of 8: the last run is handled per element
+      if (p.alpha != 1.0f) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+      }
+      if (p.bias) {
+        if (full) {
+          const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += p.bias[n0 + r];
+        }
+      }
+      if (p.out_pre) {
+        bf16* o = p.out_pre + (long)m * p.ldc + n0;
+        if (full) {
+          bf16x8 t;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+          *(bf16x8*)o = t;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+        }
+      }
+      if (ACT != CCLIP_ACT_NONE) {
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ACT >= CCLIP_ACT_DQUICKGELU) {
+          const bf16* ap = p.aux + (long)m * p.ldaux + n0;
+          if (full) {
+            const bf16x8 ax = *(const bf16x8*)ap;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] = (float)ax[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) a[r] = (float)ap[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], a[r]);
+      }
+      if (p.residual) {
+        const float* rp = p.residual + (long)m * p.ldr + n0;
+        if (full) {
+          const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+          v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += rp[r];
+        }
+      }
+      if (p.out_f32) {
+        float* o = p.out_f32 + (long)m * p.ldc + n0;
+        if (full) {
+          *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = v[r];
+        }
+      }
+      if (p.out_bf16) {
+        bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
+        if (full) {
+          bf16x8 t;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+          *(bf16x8*)o = t;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+        }
+      }
+    }
+  }
+}
+
+
+// launcher for one tile configuration; instantiates exactly the (layout, activation) pairs the hot path issues
+template <int WM, int WN, int STAGES, int MT>
+static bool gemm_launch_cfg(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a) {
+  dim3 block(64 * WM * WN);
+#define LAUNCH(AK, BKC, ACTV) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, ACTV, WM, WN, STAGES, MT>), grid, block, 0, stream, a)
+  if (lay == 3) {
+    switch (act) {
+      case CCLIP_ACT_NONE: LAUNCH(1, 1, CCLIP_ACT_NONE); return true;
+      case CCLIP_ACT_QUICKGELU: LAUNCH(1, 1, CCLIP_ACT_QUICKGELU); return true;
+      case CCLIP_ACT_TANH: LAUNCH(1, 1, CCLIP_ACT_TANH); return true;
+      case CCLIP_ACT_RELU: LAUNCH(1, 1, CCLIP_ACT_RELU); return true;
+      case CCLIP_ACT_DGELU_NEW: LAUNCH(1, 1, CCLIP_ACT_DGELU_NEW); return true;
+      default: return false;
+    }
+  } else if (lay == 2) {
+    switch (act) {
+      case CCLIP_ACT_NONE: LAUNCH(1, 0, CCLIP_ACT_NONE); return true;
+      case CCLIP_ACT_GELU_NEW: LAUNCH(1, 0, CCLIP_ACT_GELU_NEW); return true;
+      case CCLIP_ACT_DQUICKGELU: LAUNCH(1, 0, CCLIP_ACT_DQUICKGELU); return true;
+      case CCLIP_ACT_DTANH: LAUNCH(1, 0, CCLIP_ACT_DTANH); return true;
+      case CCLIP_ACT_DRELU: LAUNCH(1, 0, CCLIP_ACT_DRELU); return true;
+      default: return false;
+    }
+  }
+  if (act == CCLIP_ACT_NONE) { LAUNCH(0, 0, CCLIP_ACT_NONE); return true; }
+  return false;
+#undef LAUNCH
+}

@@ -76,6 +76,7 @@ typedef struct cclip_gemm_desc {
   int64_t ldc;
   int32_t split_k;
   float* split_ws;
+  int32_t tile_config; /* 0 = auto; 1 = 128x128 tile, 2 LDS stages; 2 = 256x128 tile, 3 stages (tuning / tests) */
 } cclip_gemm_desc;
 int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream);
 

@@ -57,9 +57,10 @@ LAYOUTS = [(True, True), (True, False), (False, False)]
 SHAPES = [(128, 128, 64), (256, 384, 192), (450, 768, 768), (264, 200, 72), (1000, 2304, 768), (72, 136, 3072)]
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3])
 @pytest.mark.parametrize("akc,bkc", LAYOUTS)
 @pytest.mark.parametrize("M,N,K", SHAPES)
-def test_gemm_plain(M, N, K, akc, bkc):
+def test_gemm_plain(M, N, K, akc, bkc, cfg):
     ops = _ops()
     if not akc and M % 8:
         pytest.skip("a_kcontig=0 needs M % 8 == 0")
@@ -70,9 +71,9 @@ def test_gemm_plain(M, N, K, akc, bkc):
     Bm = B.float() if bkc else B.float().t()
     ref = Am @ Bm.t()
     out = torch.full((M, N), float("nan"), device="cuda")
-    ops.gemm_bf16(A, B, a_kcontig=akc, b_kcontig=bkc, out_f32=out)
+    ops.gemm_bf16(A, B, a_kcontig=akc, b_kcontig=bkc, out_f32=out, tile_config=cfg)
     torch.cuda.synchronize()
-    _report(f"plain {M}x{N}x{K} {akc}{bkc}", out, ref, 2e-3)
+    _report(f"plain {M}x{N}x{K} {akc}{bkc} cfg{cfg}", out, ref, 2e-3)
 
 
 @pytest.mark.parametrize("act,akc,bkc", [(1, True, True), (2, True, True), (4, True, True), (18, True, True),
@@ -117,8 +118,9 @@ def test_gemm_residual_inplace_and_ld():
     _report("inplace", x, ref, 2e-3)
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3])
 @pytest.mark.parametrize("splits", [2, 5, 16])
-def test_gemm_wgrad_splitk(splits):
+def test_gemm_wgrad_splitk(splits, cfg):
     """wgrad layout (0,0) with ragged contraction (tokens) and split-K slabs + accumulate into grad."""
     ops = _ops()
     T, N, K = 1000 + 8, 256, 384      # contraction = tokens
@@ -128,7 +130,8 @@ def test_gemm_wgrad_splitk(splits):
     grad = torch.randn(N, K, device="cuda", generator=g)
     ref = grad + dY.float().t() @ X.float()
     ws = torch.empty(splits * N * K, device="cuda")
-    ops.gemm_bf16(dY, X, a_kcontig=False, b_kcontig=False, residual=grad, out_f32=grad, split_k=splits, split_ws=ws)
+    ops.gemm_bf16(dY, X, a_kcontig=False, b_kcontig=False, residual=grad, out_f32=grad, split_k=splits, split_ws=ws,
+                  tile_config=cfg)
     torch.cuda.synchronize()
     _report(f"wgrad split{splits}", grad, ref, 2e-3)
 
