@@ -284,10 +284,10 @@ extern "C" int cclip_add_positional(const float* emb, const float* wpe, int32_t 
 // row splits: enough blocks (~2048) to saturate HBM whatever the column count, >= 32 rows per split
 static int colsum_splits(int R, int C) {
   const int cb = (C + 511) / 512;
-  int s = (2048 + cb - 1) / cb;
-  const int smax = (R + 31) / 32;
+  int s = (1536 + cb - 1) / cb;
+  const int smax = (R + 63) / 64;
   if (s > smax) s = smax;
-  if (s > 1024) s = 1024;
+  if (s > 256) s = 256;
   return s < 1 ? 1 : s;
 }
 extern "C" int cclip_colsum_ws_floats(int32_t R, int32_t C) { return colsum_splits(R, C) * C; }

@@ -88,7 +88,7 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* tile, int col0, int nt, 
 template <int ACT>
 __device__ __forceinline__ float act_apply(float v, float a) {
   switch (ACT) {
-    case CCLIP_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
+    case CCLIP_ACT_QUICKGELU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
     case CCLIP_ACT_TANH: return tanhf(v);
     case CCLIP_ACT_GELU_NEW: {
       const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
@@ -96,7 +96,7 @@ __device__ __forceinline__ float act_apply(float v, float a) {
     }
     case CCLIP_ACT_RELU: return fmaxf(v, 0.0f);
     case CCLIP_ACT_DQUICKGELU: {   // v = upstream grad, a = saved pre-activation
-      const float s = 1.0f / (1.0f + __expf(-1.702f * a));
+      const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * a));
       return v * s * (1.0f + 1.702f * a * (1.0f - s));
     }
     case CCLIP_ACT_DTANH: return v * (1.0f - a * a);   // a = saved tanh output
@@ -202,103 +202,136 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   }
 
   // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
+  // Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then the
+  // math and the stores - one memory round trip per batch instead of one per 8-column run.
   const int li = lane & 15, g = lane >> 4;
+  float bsv[2][8];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = bm0 + wm0 + 16 * mt + li;
+  for (int h = 0; h < 2; ++h) {
+    const int n0 = bn0 + wn0 + 32 * h + 8 * g;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n0 = bn0 + wn0 + 32 * h + 8 * g;
-      if (m >= p.M || n0 >= p.N) continue;
-      float v[8];
+    for (int r = 0; r < 8; ++r) bsv[h][r] = 0.f;
+    if (p.bias && !p.split_ws && n0 < p.N) {
+      if (n0 + 8 <= p.N) {
+        const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
+        bsv[h][0] = b0.x; bsv[h][1] = b0.y; bsv[h][2] = b0.z; bsv[h][3] = b0.w;
+        bsv[h][4] = b1.x; bsv[h][5] = b1.y; bsv[h][6] = b1.z; bsv[h][7] = b1.w;
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
-      if (p.split_ws) {
-        float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
-        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-        if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        continue;
+        for (int r = 0; r < 8; ++r) if (n0 + r < p.N) bsv[h][r] = p.bias[n0 + r];
       }
-      const bool full = n0 + 8 <= p.N;          // N need not be a multiple of 8: the last run is handled per element
-      if (p.alpha != 1.0f) {
+    }
+  }
+  constexpr int EB = MT >= 8 ? 2 : 4;                      // m-tiles per epilogue batch (register budget)
+  constexpr bool HAS_AUX = ACT >= CCLIP_ACT_DQUICKGELU;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
-      }
-      if (p.bias) {
-        if (full) {
-          const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        } else {
+  for (int mb = 0; mb < MT; mb += EB) {
+    float rres[EB][2][8];
+    float raux[HAS_AUX ? EB : 1][2][8];
+    // pass 1: loads
 #pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += p.bias[n0 + r];
-        }
-      }
-      if (p.out_pre) {
-        bf16* o = p.out_pre + (long)m * p.ldc + n0;
-        if (full) {
-          bf16x8 t;
+    for (int mi = 0; mi < EB; ++mi) {
+      const int m = bm0 + wm0 + 16 * (mb + mi) + li;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-          *(bf16x8*)o = t;
-        } else {
+      for (int h = 0; h < 2; ++h) {
+        const int n0 = bn0 + wn0 + 32 * h + 8 * g;
+        const bool live = m < p.M && n0 < p.N && !p.split_ws;
+        const bool full = n0 + 8 <= p.N;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
-        }
-      }
-      if (ACT != CCLIP_ACT_NONE) {
-        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ACT >= CCLIP_ACT_DQUICKGELU) {
-          const bf16* ap = p.aux + (long)m * p.ldaux + n0;
+        for (int r = 0; r < 8; ++r) rres[mi][h][r] = 0.f;
+        if (live && p.residual) {
+          const float* rp = p.residual + (long)m * p.ldr + n0;
           if (full) {
-            const bf16x8 ax = *(const bf16x8*)ap;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a[r] = (float)ax[r];
+            const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+            rres[mi][h][0] = r0.x; rres[mi][h][1] = r0.y; rres[mi][h][2] = r0.z; rres[mi][h][3] = r0.w;
+            rres[mi][h][4] = r1.x; rres[mi][h][5] = r1.y; rres[mi][h][6] = r1.z; rres[mi][h][7] = r1.w;
           } else {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) a[r] = (float)ap[r];
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) rres[mi][h][r] = rp[r];
           }
         }
+        if (HAS_AUX) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], a[r]);
-      }
-      if (p.residual) {
-        const float* rp = p.residual + (long)m * p.ldr + n0;
-        if (full) {
-          const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
-          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-          v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        } else {
+          for (int r = 0; r < 8; ++r) raux[HAS_AUX ? mi : 0][h][r] = 0.f;
+          if (live) {
+            const bf16* ap = p.aux + (long)m * p.ldaux + n0;
+            if (full) {
+              const bf16x8 ax = *(const bf16x8*)ap;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) v[r] += rp[r];
+              for (int r = 0; r < 8; ++r) raux[HAS_AUX ? mi : 0][h][r] = (float)ax[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) if (n0 + r < p.N) raux[HAS_AUX ? mi : 0][h][r] = (float)ap[r];
+            }
+          }
         }
       }
-      if (p.out_f32) {
-        float* o = p.out_f32 + (long)m * p.ldc + n0;
-        if (full) {
+    }
+    // pass 2: math + stores
+#pragma unroll
+    for (int mi = 0; mi < EB; ++mi) {
+      const int mt = mb + mi;
+      const int m = bm0 + wm0 + 16 * mt + li;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n0 = bn0 + wn0 + 32 * h + 8 * g;
+        if (m >= p.M || n0 >= p.N) continue;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
+        if (p.split_ws) {
+          float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
           *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-          *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = v[r];
+          if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          continue;
         }
-      }
-      if (p.out_bf16) {
-        bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
-        if (full) {
-          bf16x8 t;
+        const bool full = n0 + 8 <= p.N;        // N need not be a multiple of 8: the last run is handled per element
 #pragma unroll
-          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-          *(bf16x8*)o = t;
-        } else {
+        for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bsv[h][r];
+        if (p.out_pre) {
+          bf16* o = p.out_pre + (long)m * p.ldc + n0;
+          if (full) {
+            bf16x8 t;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+            for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+            *(bf16x8*)o = t;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+          }
+        }
+        if (ACT != CCLIP_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], raux[HAS_AUX ? mi : 0][h][r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rres[mi][h][r];
+        if (p.out_f32) {
+          float* o = p.out_f32 + (long)m * p.ldc + n0;
+          if (full) {
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = v[r];
+          }
+        }
+        if (p.out_bf16) {
+          bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
+          if (full) {
+            bf16x8 t;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+            *(bf16x8*)o = t;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+          }
         }
       }
     }
   }
 }
-
 
 // launcher for one tile configuration; instantiates exactly the (layout, activation) pairs the hot path issues
 template <int WM, int WN, int STAGES, int MT>
