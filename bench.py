@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "fwd"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="ViT-B/32")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit MFMA operand type")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -118,7 +119,7 @@ def main():
     geo = MODELS[args.model]
     B = args.batch
 
-    model = clip.build_model(init_state_dict(geo, 567)).to(dev)
+    model = clip.build_model(init_state_dict(geo, 567), torch.bfloat16 if args.dtype == "bf16" else torch.float16).to(dev)
     model.train()
     parallel.broadcast_parameters(model)
     opt = coptim.AdamW(model, lr=1e-5)                       # CLIP/train.py:143 (HF AdamW, lr 1e-5)
@@ -201,7 +202,7 @@ def main():
             "metric": "image-text pairs/sec (encode+logits) ViT-B/32 bs=1024 at 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("CLIP/train.py contrastive fine-tune step (fwd+bwd+AdamW)" if args.mode == "train"
                                     else "encode_image+encode_text+logits forward only") + f", {args.model}, bs={B}/GPU, "
                        "224x224 N(0,1) images + 77-token captions, seeded synthetic weights",

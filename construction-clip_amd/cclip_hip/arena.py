@@ -20,7 +20,7 @@ _ALIGN = 64  # elements; keeps every view 256-byte (fp32) / 128-byte (bf16) alig
 
 
 class ParamArena:
-    def __init__(self, module: nn.Module, device: torch.device):
+    def __init__(self, module: nn.Module, device: torch.device, shadow_dtype: torch.dtype = torch.bfloat16):
         named: List[Tuple[str, nn.Parameter]] = list(module.named_parameters())
         self.device = device
         self.names = [n for n, _ in named]
@@ -32,7 +32,8 @@ class ParamArena:
         self.total = total
         self.flat = torch.zeros(total, device=device, dtype=torch.float32)
         self.gflat = torch.zeros(total, device=device, dtype=torch.float32)
-        self.bflat = torch.zeros(total, device=device, dtype=torch.bfloat16)
+        self.shadow_dtype = shadow_dtype          # 16-bit MFMA operand type: bfloat16 (default) or float16
+        self.bflat = torch.zeros(total, device=device, dtype=shadow_dtype)
         self.params: Dict[str, nn.Parameter] = {}
         self.g: Dict[str, torch.Tensor] = {}
         self.b: Dict[str, torch.Tensor] = {}

@@ -37,6 +37,31 @@ def _req(t: torch.Tensor, dtype, name: str):
         raise TypeError(f"{name}: expected cuda {dtype}, got {t.device} {t.dtype}")
 
 
+HALF_TYPES = (torch.bfloat16, torch.float16)
+
+
+def _req16(t: torch.Tensor, name: str):
+    if t.dtype not in HALF_TYPES or not t.is_cuda:
+        raise TypeError(f"{name}: expected cuda bfloat16/float16, got {t.device} {t.dtype}")
+
+
+def _fn(base: str, *tensors):
+    """Pick the bf16 or the fp16 twin of an entry point from the dtype of its 16-bit tensors (which must agree)."""
+    kinds = {t.dtype for t in tensors if t is not None and t.dtype in HALF_TYPES}
+    if len(kinds) > 1:
+        raise TypeError(f"{base}: mixed bfloat16 / float16 operands")
+    f16 = kinds == {torch.float16}
+    if base == "cclip_gemm_bf16":
+        return lib.cclip_gemm_f16 if f16 else lib.cclip_gemm_bf16
+    if base == "cclip_cast_f32_to_bf16":
+        return lib.cclip_cast_f32_to_f16 if f16 else lib.cclip_cast_f32_to_bf16
+    return getattr(lib, base + "_f16") if f16 else getattr(lib, base)
+
+
+def _is16(t) -> int:
+    return int(t is not None and t.dtype in HALF_TYPES)
+
+
 class GemmDesc(ctypes.Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p),
@@ -64,7 +89,7 @@ _TUNE_MIN_FLOPS = 2.0 * (1 << 29)
 
 
 def _launch_gemm(d) -> None:
-    check(lib.cclip_gemm_bf16(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
+    check(d._fn(ctypes.byref(d), _stream()), "cclip_gemm_bf16")
 
 
 def _time_desc(d, reps: int = 3) -> float:
@@ -115,7 +140,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     A: [M,K] (a_kcontig) or [K,M]; B: [N,K] (b_kcontig) or [K,N]; 2-D, inner stride 1.
     split_candidates (wgrad): list of (tile_config, split_k) to autotune over; `scratch(n)` returns an fp32
     workspace of n floats for the chosen split."""
-    _req(A, torch.bfloat16, "A"); _req(B, torch.bfloat16, "B")
+    _req16(A, "A"); _req16(B, "B")
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     Mx, K = (A.shape[0], A.shape[1]) if a_kcontig else (A.shape[1], A.shape[0])
     N, Kb = (B.shape[0], B.shape[1]) if b_kcontig else (B.shape[1], B.shape[0])
@@ -129,6 +154,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     for t in outs:
         assert t.stride(0) == ldc and t.stride(1) == 1 and t.shape[0] >= M and t.shape[1] == N
     d = GemmDesc()
+    d._fn = _fn("cclip_gemm_bf16", A, B, aux, out_bf16, out_pre)
     d.A, d.B = A.data_ptr(), B.data_ptr()
     d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
     d.lda, d.ldb = A.stride(0), B.stride(0)
@@ -154,7 +180,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     if out_f32 is not None:
         _req(out_f32, torch.float32, "out_f32")
     if tile_config == 0 and AUTOTUNE and 2.0 * M * N * K >= _TUNE_MIN_FLOPS and (outs[0].is_contiguous() or True):
-        key = (M, N, K, a_kcontig, b_kcontig, act, out_f32 is not None, out_bf16 is not None, out_pre is not None,
+        key = (A.dtype, M, N, K, a_kcontig, b_kcontig, act, out_f32 is not None, out_bf16 is not None, out_pre is not None,
                residual is not None, bias is not None, split_k if split_candidates is None else -1)
         choice = _TUNED.get(key)
         if choice is None:
@@ -186,7 +212,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, r
     _req(x, torch.float32, "x")
     D = x.shape[-1]
     out = out_bf16 if out_bf16 is not None else out_f32
-    check(lib.cclip_layernorm_fwd(_p(x), c_long(x.stride(-2)), _p(row_index), c_int(rows), c_int(D), _p(gamma), _p(beta),
+    check(_fn("cclip_layernorm_fwd", out_bf16)(_p(x), c_long(x.stride(-2)), _p(row_index), c_int(rows), c_int(D), _p(gamma), _p(beta),
                                   c_float(eps), _p(out_bf16), _p(out_f32), c_long(out.stride(-2)), _p(mean), _p(rstd),
                                   _stream()), "cclip_layernorm_fwd")
 
@@ -205,7 +231,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
         assert dx_res.stride(-2) == lddx
     if dx_out is not None and dx_out_bf16 is not None:
         assert dx_out.stride(-2) == dx_out_bf16.stride(-2)
-    check(lib.cclip_layernorm_bwd(_p(dy), c_int(int(dy.dtype == torch.bfloat16)), c_long(dy.stride(-2)), _p(x),
+    check(_fn("cclip_layernorm_bwd", dy, dx_out_bf16)(_p(dy), c_int(_is16(dy)), c_long(dy.stride(-2)), _p(x),
                                   c_long(x.stride(-2)), _p(row_index), c_int(rows), c_int(D), _p(gamma), _p(mean),
                                   _p(rstd), _p(dx_res), _p(dx_out), _p(dx_out_bf16), c_long(lddx), _p(dgamma),
                                   _p(dbeta), c_int(int(accumulate)), _p(ws), _stream()), "cclip_layernorm_bwd")
@@ -230,7 +256,7 @@ class AttnDesc(ctypes.Structure):
 
 def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale):
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
-        _req(t, torch.bfloat16, n)
+        _req16(t, n)
         assert t.stride(-1) == 1
     d = AttnDesc()
     d.q, d.k, d.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
@@ -246,7 +272,7 @@ def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale):
 def attention_fwd(q, k, v, o, *, B: int, T: int, H: int, causal: bool = False, key_keep=None, lse=None, scale=None) -> None:
     """q/k/v/o: bf16 2-D views [B*T, >= H*64] (any row stride, inner stride 1); head h at columns h*64.."""
     d = _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale)
-    check(lib.cclip_attention_fwd(ctypes.byref(d), _stream()), "cclip_attention_fwd")
+    check(_fn("cclip_attention_fwd", q, k, v, o)(ctypes.byref(d), _stream()), "cclip_attention_fwd")
 
 
 def attention_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H: int, causal: bool = False, key_keep=None,
@@ -255,7 +281,7 @@ def attention_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H: int, 
     d.dout, d.lddo = dout.data_ptr(), dout.stride(-2)
     d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     d.lddq, d.lddk, d.lddv = dq.stride(-2), dk.stride(-2), dv.stride(-2)
-    check(lib.cclip_attention_bwd(ctypes.byref(d), _stream()), "cclip_attention_bwd")
+    check(_fn("cclip_attention_bwd", q, k, v, o, dout, dq, dk, dv)(ctypes.byref(d), _stream()), "cclip_attention_bwd")
 
 
 # --------------------------------------------------------------------------------------------
@@ -279,7 +305,7 @@ def gemm_f32(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, *, alpha: float 
 def patchify(image: torch.Tensor, out_bf16: torch.Tensor, P: int) -> None:
     _req(image, torch.float32, "image")
     assert image.is_contiguous() and image.dim() == 4 and image.shape[1] == 3 and image.shape[2] == image.shape[3]
-    check(lib.cclip_patchify(_p(image), _p(out_bf16), c_int(image.shape[0]), c_int(image.shape[2]), c_int(P), _stream()),
+    check(_fn("cclip_patchify", out_bf16)(_p(image), _p(out_bf16), c_int(image.shape[0]), c_int(image.shape[2]), c_int(P), _stream()),
           "cclip_patchify")
 
 
@@ -319,7 +345,7 @@ def colsum_ws_floats(R: int, C: int) -> int:
 
 
 def colsum(inp: torch.Tensor, out: torch.Tensor, ws: torch.Tensor, *, R: int, C: int, ld: int, accumulate: bool = False):
-    check(lib.cclip_colsum(_p(inp), c_int(int(inp.dtype == torch.bfloat16)), c_long(ld), c_int(R), c_int(C), _p(out),
+    check(_fn("cclip_colsum", inp)(_p(inp), c_int(_is16(inp)), c_long(ld), c_int(R), c_int(C), _p(out),
                            c_int(int(accumulate)), _p(ws), _stream()), "cclip_colsum")
 
 
@@ -340,9 +366,9 @@ def xent_rows(logits, labels_i32, *, loss_row=None, pred=None, dlogits=None, gra
               ignore_index: int = -100, rowdot=None) -> None:
     _req(logits, torch.float32, "logits"); _req(labels_i32, torch.int32, "labels")
     R, C = logits.shape
-    check(lib.cclip_xent_rows(_p(logits), c_long(logits.stride(0)), c_int(R), c_int(C), _p(labels_i32), c_int(ignore_index),
+    check(_fn("cclip_xent_rows", dlogits)(_p(logits), c_long(logits.stride(0)), c_int(R), c_int(C), _p(labels_i32), c_int(ignore_index),
                               c_float(grad_scale), _p(loss_row), _p(pred), _p(dlogits),
-                              c_int(int(dlogits is not None and dlogits.dtype == torch.bfloat16)),
+                              c_int(_is16(dlogits)),
                               c_long(0 if dlogits is None else dlogits.stride(0)), _p(rowdot), _stream()), "cclip_xent_rows")
 
 
@@ -357,10 +383,10 @@ def reduce_dot(a, b, out, *, alpha: float = 1.0, mul_dev=None, accumulate: bool 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr: float, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.0,
                step: int = 1, correct_bias: bool = True, grad_scale: float = 1.0, mode: int = 0, bf16_shadow=None):
     n = param.numel()
-    check(lib.cclip_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), c_long(n), c_float(lr), c_float(beta1),
+    check(_fn("cclip_adamw_step", bf16_shadow)(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), c_long(n), c_float(lr), c_float(beta1),
                                c_float(beta2), c_float(eps), c_float(weight_decay), c_int(step), c_int(int(correct_bias)),
                                c_float(grad_scale), c_int(mode), _p(bf16_shadow), _stream()), "cclip_adamw_step")
 
 
 def cast_f32_to_bf16(src, dst) -> None:
-    check(lib.cclip_cast_f32_to_bf16(_p(src), _p(dst), c_long(src.numel()), _stream()), "cclip_cast_f32_to_bf16")
+    check(_fn("cclip_cast_f32_to_bf16", dst)(_p(src), _p(dst), c_long(src.numel()), _stream()), "cclip_cast_f32_to_bf16")

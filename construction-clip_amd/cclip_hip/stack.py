@@ -88,8 +88,9 @@ class Scratch:
 
 
 class BlockStack:
-    def __init__(self, geo: StackGeometry, blocks: List[BlockWeights], scratch: Scratch):
-        self.geo, self.blocks, self.scratch = geo, blocks, scratch
+    def __init__(self, geo: StackGeometry, blocks: List[BlockWeights], scratch: Scratch,
+                 dtype: torch.dtype = torch.bfloat16):
+        self.geo, self.blocks, self.scratch, self.dtype = geo, blocks, scratch, dtype
 
     # ------------------------------------------------------------------ forward
     def alloc_saved(self, B: int, device, T: Optional[int] = None) -> dict:
@@ -99,7 +100,7 @@ class BlockStack:
         T = T or self.geo.tokens
         M, L = B * T, len(self.blocks)
         return dict(T=T,
-            bf=torch.empty(L, M, 14 * D, device=device, dtype=torch.bfloat16),   # xn1 | qkv | a | xn2 | h | g
+            bf=torch.empty(L, M, 14 * D, device=device, dtype=self.dtype),   # xn1 | qkv | a | xn2 | h | g
             xs=torch.empty(L, 2, M, D, device=device, dtype=torch.float32),      # x_in, x_mid
             st=torch.empty(L, 4, M, device=device, dtype=torch.float32),         # mean1 rstd1 mean2 rstd2
             lse=torch.empty(L, B, H, T, device=device, dtype=torch.float32),
@@ -122,7 +123,7 @@ class BlockStack:
             bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
             saved["key_keep"] = key_keep
         else:
-            bf = torch.empty(M, 10 * D, device=dev, dtype=torch.bfloat16)      # xn | qkv | a | - | g  (reused per layer)
+            bf = torch.empty(M, 10 * D, device=dev, dtype=self.dtype)      # xn | qkv | a | - | g  (reused per layer)
         for l, w in enumerate(self.blocks):
             if train:
                 row = bf[l]
@@ -173,7 +174,7 @@ class BlockStack:
         kc = geo.linear_layout
         dact = _DACT[geo.act]
         bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
-        tmp = torch.empty(M, 8 * D, device=dev, dtype=torch.bfloat16)      # dh | dqkv | dxn / da
+        tmp = torch.empty(M, 8 * D, device=dev, dtype=self.dtype)      # dh | dqkv | dxn / da
         dh, dqkv, dsm = tmp[:, 0:4 * D], tmp[:, 4 * D:7 * D], tmp[:, 7 * D:8 * D]
         ln_ws = self.scratch  # partial sums live in scratch; sized per call
         for l in range(len(self.blocks) - 1, -1, -1):

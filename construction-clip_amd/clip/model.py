@@ -124,9 +124,11 @@ def _require_cuda(t: torch.Tensor, what: str):
 
 # ------------------------------------------------------------------------------------------------
 class CLIP(nn.Module):
-    def __init__(self, geo: CLIPGeometry):
+    def __init__(self, geo: CLIPGeometry, compute_dtype: torch.dtype = torch.bfloat16):
         super().__init__()
+        assert compute_dtype in (torch.bfloat16, torch.float16)
         self.geo = geo
+        self.compute_dtype = compute_dtype      # 16-bit MFMA operand type (masters, residual stream, head stay fp32)
         self.context_length = geo.context_length
         self.vocab_size = geo.vocab_size
         self.visual = VisionTransformer(geo)
@@ -152,7 +154,17 @@ class CLIP(nn.Module):
     def float(self):          # masters are always fp32; nothing to convert
         return self
 
-    def half(self):           # the reference's fp16 CUDA weights map to bf16 shadows here
+    def half(self):           # fp16 MFMA operands (the reference's CUDA dtype; 8x finer than bf16: parity mode)
+        return self.set_compute_dtype(torch.float16)
+
+    def bfloat16(self):       # bf16 MFMA operands (default; training range)
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.bfloat16, torch.float16)
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._arena, self._rt = None, None
         return self
 
     @property
@@ -167,7 +179,7 @@ class CLIP(nn.Module):
                                "the HIP kernels are the only compute path" % dev)
         if self._arena is not None and self._arena.intact():
             return
-        ar = ParamArena(self, dev)
+        ar = ParamArena(self, dev, self.compute_dtype)
         geo = self.geo
 
         def stack(prefix: str, width: int, heads: int, layers: int, tokens: int, causal: bool) -> BlockStack:
@@ -179,7 +191,8 @@ class CLIP(nn.Module):
                     kw[f] = ar.b[name] if f in _MATS else ar.params[name].data
                     grads[f] = ar.g[name]
                 blocks.append(BlockWeights(grads=grads, **kw))
-            return BlockStack(StackGeometry(width, heads, tokens, True, ops.ACT_QUICKGELU, causal), blocks, Scratch(dev))
+            return BlockStack(StackGeometry(width, heads, tokens, True, ops.ACT_QUICKGELU, causal), blocks, Scratch(dev),
+                              self.compute_dtype)
 
         self._arena = ar
         self._rt = dict(
@@ -206,7 +219,7 @@ class CLIP(nn.Module):
             raise RuntimeError(f"encode_image: expected [N,3,{geo.image_resolution},{geo.image_resolution}], got {tuple(image.shape)}")
         M = B * T
         img = image.detach().to(torch.float32).contiguous()
-        patches = torch.empty(M, 3 * P * P, device=dev, dtype=torch.bfloat16)
+        patches = torch.empty(M, 3 * P * P, device=dev, dtype=self.compute_dtype)
         ops.patchify(img, patches, P)
         patch_out = torch.empty(M, D, device=dev, dtype=torch.float32)
         ops.gemm_bf16(patches, ar.b["visual.conv1.weight"].view(D, -1), out_f32=patch_out)
@@ -245,7 +258,7 @@ class CLIP(nn.Module):
         dpooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         ops.gemm_f32(dfeat, p["visual.proj"].data, dpooled)
         dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
-        dxb = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+        dxb = torch.zeros(M, D, device=dev, dtype=self.compute_dtype)
         sc = st.scratch
         ops.layernorm_bwd(dpooled, c["xo"], p["visual.ln_post.weight"].data, c["stp"][0], c["stp"][1], rows=B,
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["visual.ln_post.weight"],
@@ -306,7 +319,7 @@ class CLIP(nn.Module):
         dpooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         ops.gemm_f32(dfeat, p["text_projection"].data, dpooled)
         dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
-        dxb = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+        dxb = torch.zeros(M, D, device=dev, dtype=self.compute_dtype)
         sc = st.scratch
         ops.layernorm_bwd(dpooled, c["xo"], p["ln_final.weight"].data, c["stp"][0], c["stp"][1], rows=B,
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["ln_final.weight"],
@@ -417,9 +430,9 @@ class _Logits(torch.autograd.Function):
         return dfi, dft, dscale.reshape(())
 
 
-def build_model(state_dict: Dict[str, torch.Tensor]) -> CLIP:
+def build_model(state_dict: Dict[str, torch.Tensor], compute_dtype: torch.dtype = torch.bfloat16) -> CLIP:
     """openai/CLIP's build_model(): geometry from tensor shapes, then load (CLIP/train.py:111 round trip)."""
     sd = {k: v for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
-    model = CLIP(geometry_from_state_dict(sd))
+    model = CLIP(geometry_from_state_dict(sd), compute_dtype)
     model.load_state_dict(sd)
     return model.eval()

@@ -190,6 +190,23 @@ class ClipCaptionModel(nn.Module):
         self.clip_project._owner = ref
         self._arena: Optional[ParamArena] = None
         self._stack: Optional[BlockStack] = None
+        self.compute_dtype = torch.bfloat16
+
+    def half(self):
+        return self.set_compute_dtype(torch.float16)
+
+    def bfloat16(self):
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def float(self):
+        return self
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.bfloat16, torch.float16)
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._arena = self._stack = None
+        return self
 
     @property
     def gpt(self):            # test.py / application.py name the same submodule `gpt`
@@ -223,7 +240,7 @@ class ClipCaptionModel(nn.Module):
             raise RuntimeError(f"ClipCaptionModel parameters are on {dev}: the HIP kernels are the only compute path")
         if self._arena is not None and self._arena.intact():
             return
-        ar = ParamArena(self, dev)
+        ar = ParamArena(self, dev, self.compute_dtype)
         g = self.model.geo
         blocks = []
         for i in range(g.n_layer):
@@ -234,7 +251,8 @@ class ClipCaptionModel(nn.Module):
                 grads[f] = ar.g[name] if ar.params[name].requires_grad else None
             blocks.append(BlockWeights(grads=grads if all(v is not None for v in grads.values()) else None, **kw))
         self._arena = ar
-        self._stack = BlockStack(StackGeometry(g.n_embd, g.n_head, 0, False, ops.ACT_GELU_NEW, True), blocks, Scratch(dev))
+        self._stack = BlockStack(StackGeometry(g.n_embd, g.n_head, 0, False, ops.ACT_GELU_NEW, True), blocks, Scratch(dev),
+                                 self.compute_dtype)
 
     # ---- mapper ----
     def _mapper_forward(self, prefix: torch.Tensor, train: bool):
@@ -242,9 +260,9 @@ class ClipCaptionModel(nn.Module):
         B = prefix.shape[0]
         dev = prefix.device
         n_in, n_hid, n_out = self.clip_project.sizes
-        pb = torch.empty(B, n_in, device=dev, dtype=torch.bfloat16)
+        pb = torch.empty(B, n_in, device=dev, dtype=self.compute_dtype)
         ops.cast_f32_to_bf16(prefix.detach().float().contiguous(), pb)
-        h1 = torch.empty(B, n_hid, device=dev, dtype=torch.bfloat16)
+        h1 = torch.empty(B, n_hid, device=dev, dtype=self.compute_dtype)
         ops.gemm_bf16(pb, ar.b["clip_project.model.0.weight"], bias=ar.params["clip_project.model.0.bias"].data,
                       act=ops.ACT_TANH, out_bf16=h1)
         out = torch.empty(B, n_out, device=dev, dtype=torch.float32)
@@ -273,7 +291,7 @@ class ClipCaptionModel(nn.Module):
         p = ar.params
         R, D = rows.numel(), self.model_embedding_size
         dev = xo.device
-        xf = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
+        xf = torch.empty(R, D, device=dev, dtype=self.compute_dtype)
         st = torch.empty(2, R, device=dev, dtype=torch.float32)
         ops.layernorm_fwd(xo, p["model.transformer.ln_f.weight"].data, p["model.transformer.ln_f.bias"].data, rows=R,
                           row_index=rows, out_bf16=xf, mean=st[0], rstd=st[1])
@@ -364,10 +382,10 @@ class ClipCaptionModel(nn.Module):
             ops.gemm_bf16(dlog_b, xf, a_kcontig=False, b_kcontig=False, residual=g[wte_name] if A(wte_name) else None,
                           out_f32=g[wte_name], split_candidates=wgrad_candidates(n_out, k_in, R), scratch=sc.floats)
             wrote_wte = True
-        dxf = torch.empty(R, D, device=dev, dtype=torch.bfloat16)
+        dxf = torch.empty(R, D, device=dev, dtype=self.compute_dtype)
         ops.gemm_bf16(dlog_b, ar.b[wte_name], b_kcontig=False, out_bf16=dxf)           # dlogits @ wte
         dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
-        dxb = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+        dxb = torch.zeros(M, D, device=dev, dtype=self.compute_dtype)
         lnf_w, lnf_b = "model.transformer.ln_f.weight", "model.transformer.ln_f.bias"
         ops.layernorm_bwd(dxf, c["xo"], p[lnf_w].data, st[0], st[1], rows=R, row_index=rows, dx_out=dx, dx_out_bf16=dxb,
                           dgamma=None if frozen else g[lnf_w], dbeta=None if frozen else g[lnf_b],
@@ -390,7 +408,7 @@ class ClipCaptionModel(nn.Module):
                               "clip_project.model.2.bias")
             ops.gemm_bf16(dproj, h1, a_kcontig=False, b_kcontig=False, residual=g[w2] if A(w2) else None, out_f32=g[w2])
             ops.colsum(dproj, g[b2], sc.floats(ops.colsum_ws_floats(B, n_out)), R=B, C=n_out, ld=S * D, accumulate=A(b2))
-            dh1 = torch.empty(B, n_hid, device=dev, dtype=torch.bfloat16)
+            dh1 = torch.empty(B, n_hid, device=dev, dtype=self.compute_dtype)
             ops.gemm_bf16(dproj, ar.b[w2], b_kcontig=False, act=ops.ACT_DTANH, aux=h1, out_bf16=dh1)
             ops.gemm_bf16(dh1, pb, a_kcontig=False, b_kcontig=False, residual=g[w0] if A(w0) else None, out_f32=g[w0])
             ops.colsum(dh1, g[b0], sc.floats(ops.colsum_ws_floats(B, n_hid)), R=B, C=n_hid, ld=n_hid, accumulate=A(b0))
@@ -428,7 +446,7 @@ class _CaptionLogits(torch.autograd.Function):
         Vp = (V + 7) // 8 * 8
         d = torch.zeros(R, Vp, device=dlogits.device, dtype=torch.float32)
         d[:, :V].copy_(dlogits)                                             # re-stride onto the 8-padded layout (plumbing)
-        db = torch.empty(R, Vp, device=d.device, dtype=torch.bfloat16)
+        db = torch.empty(R, Vp, device=d.device, dtype=ctx.model.compute_dtype)
         ops.cast_f32_to_bf16(d, db)
         ctx.model._backward_from_dlogits(ctx.c, db[:, :V], ctx.rows, ctx.lm)
         ctx.c = ctx.lm = None
@@ -450,7 +468,7 @@ class _CaptionLoss(torch.autograd.Function):
         R = rows.numel()
         loss_rows = torch.empty(R, device=dev, dtype=torch.float32)
         V = logits.shape[1]
-        dlog = torch.zeros(R, (V + 7) // 8 * 8, device=dev, dtype=torch.bfloat16)[:, :V] if need_grad else None   # finite pads
+        dlog = torch.zeros(R, (V + 7) // 8 * 8, device=dev, dtype=model.compute_dtype)[:, :V] if need_grad else None   # finite pads
         ops.xent_rows(logits, labels, loss_row=loss_rows, dlogits=dlog, grad_scale=1.0 / max(kept, 1), ignore_index=0)
         out = torch.empty(1, device=dev, dtype=torch.float32)
         ops.reduce_dot(loss_rows, None, out, alpha=1.0 / max(kept, 1))

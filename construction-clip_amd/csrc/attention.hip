@@ -20,6 +20,8 @@
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
+namespace CCLIP_NS {
+
 struct AttnArgs {
   const bf16* q; const bf16* k; const bf16* v;   // row (b*T + t), head h at column h*64
   long ldq, ldk, ldv;
@@ -85,8 +87,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     for (int kt = 0; kt < NKT; ++kt) {
       s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (kt <= ktmax) {
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, 16 * kt + li, g), qf0, s[kt], 0, 0, 0);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, 16 * kt + li, 4 + g), qf1, s[kt], 0, 0, 0);
+        s[kt] = CCLIP_MFMA_16x16x32(frag_row(Ks, 16 * kt + li, g), qf0, s[kt]);
+        s[kt] = CCLIP_MFMA_16x16x32(frag_row(Ks, 16 * kt + li, 4 + g), qf1, s[kt]);
       }
     }
     float m = NEG;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, o[dt], 0, 0, 0);
+          o[dt] = CCLIP_MFMA_16x16x32(frag_tr(Vs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, o[dt]);
       }
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -209,10 +211,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
         const int qt = 2 * ss + half;
         f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int qrow = 16 * qt + li;                     // A-operand row of this lane (row read)
-        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, g), kf0, sv, 0, 0, 0);
-        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, 4 + g), kf1, sv, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, g), vf0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, 4 + g), vf1, dp, 0, 0, 0);
+        sv = CCLIP_MFMA_16x16x32(frag_row(Qs, qrow, g), kf0, sv);
+        sv = CCLIP_MFMA_16x16x32(frag_row(Qs, qrow, 4 + g), kf1, sv);
+        dp = CCLIP_MFMA_16x16x32(frag_row(Os, qrow, g), vf0, dp);
+        dp = CCLIP_MFMA_16x16x32(frag_row(Os, qrow, 4 + g), vf1, dp);
         const float4 ls = *(const float4*)(lse_s + 16 * qt + 4 * g);
         const float4 de = *(const float4*)(del_s + 16 * qt + 4 * g);
         const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
       // contraction over the 32 queries of this pair: k index = (half, g, r) on both operands
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dvT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Os, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, dvT[dt], 0, 0, 0);
-        dkT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), dsf, dkT[dt], 0, 0, 0);
+        dvT[dt] = CCLIP_MFMA_16x16x32(frag_tr(Os, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, dvT[dt]);
+        dkT[dt] = CCLIP_MFMA_16x16x32(frag_tr(Qs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), dsf, dkT[dt]);
       }
     }
     if (key < T) {
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
       const bf16x8 dsf = *(const bf16x8*)(dSs + qi * DS_LD + (32 * ss + 8 * g) * 2);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        dqT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Ks, 32 * ss + 8 * g, 32 * ss + 8 * g + 4, dt, lane), dsf, dqT[dt], 0, 0, 0);
+        dqT[dt] = CCLIP_MFMA_16x16x32(frag_tr(Ks, 32 * ss + 8 * g, 32 * ss + 8 * g + 4, dt, lane), dsf, dqT[dt]);
     }
     if (qi < T) {
       bf16* dqp = a.dq + (row0 + qi) * a.lddq + h * 64 + 4 * g;
@@ -270,6 +272,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
     }
   }
 }
+
+}  // namespace CCLIP_NS
+using namespace CCLIP_NS;
 
 static bool attn_args_ok(const cclip_attn_desc* d, bool bwd) {
   if (!d || !d->q || !d->k || !d->v || !d->o) return false;
@@ -296,7 +301,7 @@ static AttnArgs attn_pack(const cclip_attn_desc* d) {
   return a;
 }
 
-extern "C" int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream) {
+extern "C" int CCLIP_FN(cclip_attention_fwd)(const cclip_attn_desc* d, hipStream_t stream) {
   if (!attn_args_ok(d, false)) return CCLIP_ERR_ARG;
   const AttnArgs a = attn_pack(d);
   dim3 grid(d->B * d->H), block(256);
@@ -308,7 +313,7 @@ extern "C" int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream)
   return cclip_launch_status();
 }
 
-extern "C" int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream) {
+extern "C" int CCLIP_FN(cclip_attention_bwd)(const cclip_attn_desc* d, hipStream_t stream) {
   if (!attn_args_ok(d, true)) return CCLIP_ERR_ARG;
   const AttnArgs a = attn_pack(d);
   dim3 grid(d->B * d->H), block(256);

@@ -29,12 +29,26 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+# translation units that touch 16-bit operands are built twice: bf16 (default) and IEEE fp16 (-DCCLIP_F16)
+DUAL = ("gemm_bf16", "attention", "layernorm", "embed", "loss", "optim")
+
+
+def _jobs():
+    jobs = []
+    for src in _sources():
+        jobs.append((src, False))
+        if src.startswith(DUAL):
+            jobs.append((src, True))
+    return jobs
+
+
+def _compile(job, force: bool) -> str:
+    src, f16 = job
+    obj = os.path.join(OBJ_DIR, src[:-4] + ("_f16" if f16 else "") + ".o")
     spath = os.path.join(HERE, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _deps_mtime()):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", spath, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *(["-DCCLIP_F16"] if f16 else []), "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -43,8 +57,8 @@ def _compile(src: str, force: bool) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
-    srcs = _sources()
-    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+    srcs = _jobs()
+    with ThreadPoolExecutor(max_workers=min(7, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
@@ -52,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"[cclip_hip] built {LIB} from {len(srcs)} sources")
+        print(f"[cclip_hip] built {LIB} from {len(srcs)} objects")
     return LIB
 
 

@@ -11,6 +11,8 @@
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
+namespace CCLIP_NS {
+
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B,
                                                        int R, int P, int G) {
   const int T = G * G + 1, KP = 3 * P * P, chunks = KP / 8;
@@ -226,9 +228,12 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+}  // namespace CCLIP_NS
+using namespace CCLIP_NS;
+
 static int grid_rows4(int rows) { int g = (rows + 3) / 4; return g > 4096 ? 4096 : (g < 1 ? 1 : g); }
 
-extern "C" int cclip_patchify(const float* image, void* out_bf16, int32_t B, int32_t R, int32_t P, hipStream_t stream) {
+extern "C" int CCLIP_FN(cclip_patchify)(const float* image, void* out_bf16, int32_t B, int32_t R, int32_t P, hipStream_t stream) {
   if (!image || !out_bf16 || B <= 0 || P <= 0 || R % P || (P & 7) || ((uintptr_t)image & 15)) return CCLIP_ERR_ARG;
   const int G = R / P;
   const long total = (long)B * (G * G + 1) * (3 * P * P / 8);
@@ -237,6 +242,7 @@ extern "C" int cclip_patchify(const float* image, void* out_bf16, int32_t B, int
   return cclip_launch_status();
 }
 
+#ifndef CCLIP_F16
 extern "C" int cclip_vit_embed_ln(const float* patch_out, const float* cls, const float* pos, int32_t rows, int32_t T,
                                   int32_t D, const float* gamma, const float* beta, float eps, float* x0, float* x,
                                   float* mean, float* rstd, hipStream_t stream) {
@@ -248,14 +254,18 @@ extern "C" int cclip_vit_embed_ln(const float* patch_out, const float* cls, cons
 #undef VE
   return cclip_launch_status();
 }
+#endif
 
+#ifndef CCLIP_F16
 extern "C" int cclip_text_embed(const int32_t* text, const float* emb, const float* pos, int32_t rows, int32_t L,
                                 int32_t D, int32_t V, float* x, hipStream_t stream) {
   if (!text || !emb || !x || rows <= 0 || L <= 0 || (D & 3) || V <= 0) return CCLIP_ERR_ARG;
   hipLaunchKernelGGL(text_embed_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, text, emb, pos, rows, L, D, V, x);
   return cclip_launch_status();
 }
+#endif
 
+#ifndef CCLIP_F16
 extern "C" int cclip_embed_scatter_add(const int32_t* text, const float* dx, int64_t lddx, int32_t rows, int32_t D,
                                        int32_t V, float* demb, int32_t L, int32_t seq_stride, int32_t seq_off,
                                        hipStream_t stream) {
@@ -264,7 +274,9 @@ extern "C" int cclip_embed_scatter_add(const int32_t* text, const float* dx, int
                      demb, L, seq_stride, seq_off);
   return cclip_launch_status();
 }
+#endif
 
+#ifndef CCLIP_F16
 extern "C" int cclip_caption_embed(const float* prefix_proj, const int32_t* ids, const float* wte, const float* wpe,
                                    int32_t B, int32_t P, int32_t Lt, int32_t D, int32_t V, float* x, hipStream_t stream) {
   if (!wte || !wpe || !x || B <= 0 || P < 0 || Lt < 0 || P + Lt <= 0 || (D & 3) || V <= 0) return CCLIP_ERR_ARG;
@@ -273,13 +285,16 @@ extern "C" int cclip_caption_embed(const float* prefix_proj, const int32_t* ids,
                      P, Lt, D, V, x);
   return cclip_launch_status();
 }
+#endif
 
+#ifndef CCLIP_F16
 extern "C" int cclip_add_positional(const float* emb, const float* wpe, int32_t rows, int32_t S, int32_t D, float* x,
                                     hipStream_t stream) {
   if (!emb || !wpe || !x || rows <= 0 || S <= 0 || (D & 3)) return CCLIP_ERR_ARG;
   hipLaunchKernelGGL(add_pos_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, emb, wpe, rows, S, D, x);
   return cclip_launch_status();
 }
+#endif
 
 // row splits: enough blocks (~2048) to saturate HBM whatever the column count, >= 32 rows per split
 static int colsum_splits(int R, int C) {
@@ -290,8 +305,10 @@ static int colsum_splits(int R, int C) {
   if (s > 256) s = 256;
   return s < 1 ? 1 : s;
 }
+#ifndef CCLIP_F16
 extern "C" int cclip_colsum_ws_floats(int32_t R, int32_t C) { return colsum_splits(R, C) * C; }
-extern "C" int cclip_colsum(const void* in, int32_t in_is_bf16, int64_t ld, int32_t R, int32_t C, float* out,
+#endif
+extern "C" int CCLIP_FN(cclip_colsum)(const void* in, int32_t in_is_bf16, int64_t ld, int32_t R, int32_t C, float* out,
                             int32_t accumulate, float* ws, hipStream_t stream) {
   if (!in || !out || !ws || R <= 0 || C <= 0 || (C & 3) || (ld & 3)) return CCLIP_ERR_ARG;
   if (in_is_bf16 ? ((ld & 7) || ((uintptr_t)in & 15)) : ((uintptr_t)in & 15)) return CCLIP_ERR_ARG;

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include "gemm_bf16_impl.h"
 
+namespace CCLIP_NS {
 bool cclip_gemm_launch_cfg1(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg2(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg3(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
@@ -59,7 +60,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-extern "C" int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream) {
+}  // namespace CCLIP_NS
+using namespace CCLIP_NS;
+
+extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return CCLIP_ERR_ARG;
   if ((d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
   if (!d->a_kcontig && d->b_kcontig) return CCLIP_ERR_ARG;   // (0,1) is not a layout this path uses

@@ -4,6 +4,8 @@
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
+namespace CCLIP_NS {
+
 #define BK 64
 #define TILE_BYTES (128 * 64 * 2)        // one 16 KiB sub-tile: 128 rows (or columns) x 64 k
 
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], xf[ks][mt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
     }
     // schedule: 8 DS reads (k-step 0) up front, then 2 MFMA : 1 DS read while k-step 1's fragments stream in
     constexpr int RD = (A_KC ? MT : 2 * MT) + (B_KC ? 4 : 8);     // LDS read instructions per k-step
@@ -361,3 +363,5 @@ static bool gemm_launch_cfg(int lay, int act, dim3 grid, hipStream_t stream, con
   return false;
 #undef LAUNCH
 }
+
+}  // namespace CCLIP_NS

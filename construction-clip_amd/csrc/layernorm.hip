@@ -8,6 +8,8 @@
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
+namespace CCLIP_NS {
+
 #define LN_WAVES 4
 
 // NV = number of 256-element column chunks a lane covers (D <= 256*NV); lane owns cols c*256 + 4*lane .. +3
@@ -181,12 +183,15 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   }
 }
 
+}  // namespace CCLIP_NS
+using namespace CCLIP_NS;
+
 static int ln_grid(int rows) {
   int g = (rows + LN_WAVES - 1) / LN_WAVES;
   return g > 2048 ? 2048 : (g < 1 ? 1 : g);
 }
 
-extern "C" int cclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* row_index, int32_t rows, int32_t D,
+extern "C" int CCLIP_FN(cclip_layernorm_fwd)(const float* x, int64_t ldx, const int32_t* row_index, int32_t rows, int32_t D,
                                    const float* gamma, const float* beta, float eps, void* out_bf16, float* out_f32,
                                    int64_t ldo, float* mean, float* rstd, hipStream_t stream) {
   if (!x || !gamma || !beta || rows <= 0 || D <= 0 || (D & 3) || D > 1024 || (ldx & 3) || (ldo & 3)) return CCLIP_ERR_ARG;
@@ -200,9 +205,11 @@ extern "C" int cclip_layernorm_fwd(const float* x, int64_t ldx, const int32_t* r
 }
 
 static int ln_bwd_grid(int rows) { int g = ln_grid(rows); return g > 1024 ? 1024 : g; }
+#ifndef CCLIP_F16
 extern "C" int cclip_layernorm_bwd_ws_floats(int32_t rows, int32_t D) { return ln_bwd_grid(rows) * 2 * D; }
+#endif
 
-extern "C" int cclip_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx,
+extern "C" int CCLIP_FN(cclip_layernorm_bwd)(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx,
                                    const int32_t* row_index, int32_t rows, int32_t D, const float* gamma,
                                    const float* mean, const float* rstd, const float* dx_res, float* dx_out,
                                    void* dx_out_bf16, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,

@@ -11,6 +11,8 @@
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
+namespace CCLIP_NS {
+
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, long ldx, int rows, int D,
                                                          float* __restrict__ y, long ldy, float* __restrict__ inv_norm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,14 +107,20 @@ __global__ __launch_bounds__(1024) void reduce_dot_kernel(const float* __restric
   }
 }
 
+}  // namespace CCLIP_NS
+using namespace CCLIP_NS;
+
 static int grid_rows4(int rows) { int g = (rows + 3) / 4; return g > 4096 ? 4096 : (g < 1 ? 1 : g); }
 
+#ifndef CCLIP_F16
 extern "C" int cclip_l2norm_fwd(const float* x, int64_t ldx, int32_t rows, int32_t D, float* y, int64_t ldy,
                                 float* inv_norm, hipStream_t stream) {
   if (!x || !y || rows <= 0 || D <= 0) return CCLIP_ERR_ARG;
   hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, x, (long)ldx, rows, D, y, (long)ldy, inv_norm);
   return cclip_launch_status();
 }
+#endif
+#ifndef CCLIP_F16
 extern "C" int cclip_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* inv_norm,
                                 int32_t rows, int32_t D, float* dx, int64_t lddx, const float* mul_dev,
                                 hipStream_t stream) {
@@ -120,7 +128,8 @@ extern "C" int cclip_l2norm_bwd(const float* dy, int64_t lddy, const float* y, i
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, dy, (long)lddy, y, (long)ldy, inv_norm, rows, D, dx, (long)lddx, mul_dev);
   return cclip_launch_status();
 }
-extern "C" int cclip_xent_rows(const float* logits, int64_t ld, int32_t R, int32_t C, const int32_t* labels,
+#endif
+extern "C" int CCLIP_FN(cclip_xent_rows)(const float* logits, int64_t ld, int32_t R, int32_t C, const int32_t* labels,
                                int32_t ignore_index, float grad_scale, float* loss_row, int32_t* pred,
                                void* dlogits, int32_t dlogits_is_bf16, int64_t ldd, float* rowdot,
                                hipStream_t stream) {
@@ -134,9 +143,11 @@ extern "C" int cclip_xent_rows(const float* logits, int64_t ld, int32_t R, int32
   return cclip_launch_status();
 }
 
+#ifndef CCLIP_F16
 extern "C" int cclip_reduce_dot(const float* a, const float* b, int64_t n, float alpha, const float* mul_dev, float* out,
                                 int32_t accumulate, hipStream_t stream) {
   if (!a || !out || n <= 0) return CCLIP_ERR_ARG;
   hipLaunchKernelGGL(reduce_dot_kernel, dim3(1), dim3(1024), 0, stream, a, b, (long)n, alpha, mul_dev, out, accumulate);
   return cclip_launch_status();
 }
+#endif

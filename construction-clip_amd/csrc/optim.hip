@@ -12,6 +12,8 @@
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
+namespace CCLIP_NS {
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2,
@@ -54,9 +56,12 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+}  // namespace CCLIP_NS
+using namespace CCLIP_NS;
+
 static int flat_grid(long n4) { long b = (n4 + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
-extern "C" int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+extern "C" int CCLIP_FN(cclip_adamw_step)(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, int32_t step,
                                 int32_t correct_bias, float grad_scale, int32_t mode, void* bf16_shadow,
                                 hipStream_t stream) {
@@ -72,7 +77,7 @@ extern "C" int cclip_adamw_step(float* param, const float* grad, float* exp_avg,
   return cclip_launch_status();
 }
 
-extern "C" int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream) {
+extern "C" int CCLIP_CAST_FN(const float* in, void* out, int64_t n, hipStream_t stream) {
   if (!in || !out || n <= 0 || (n & 3) || ((uintptr_t)in & 15) || ((uintptr_t)out & 7)) return CCLIP_ERR_ARG;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(flat_grid(n >> 2)), dim3(256), 0, stream, in, (bf16*)out, (long)n);
   return cclip_launch_status();

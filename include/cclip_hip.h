@@ -194,6 +194,33 @@ int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      hipStream_t stream);
 int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
+/* ---- IEEE fp16 twins ---------------------------------------------------------------------------
+ * Every entry point above whose 16-bit buffers are bf16 has a twin with the identical signature that
+ * treats them as IEEE fp16 (same MFMA rate on gfx950; 3 more mantissa bits - the reference's own CUDA
+ * dtype, and the mode in which the towers meet the <= 1e-3 parity target; use bf16 for training range). */
+int cclip_gemm_f16(const cclip_gemm_desc* d, hipStream_t stream);
+int cclip_layernorm_fwd_f16(const float* x, int64_t ldx, const int32_t* row_index, int32_t rows, int32_t D,
+                            const float* gamma, const float* beta, float eps, void* out_f16, float* out_f32,
+                            int64_t ldo, float* mean, float* rstd, hipStream_t stream);
+int cclip_layernorm_bwd_f16(const void* dy, int32_t dy_is_f16, int64_t lddy, const float* x, int64_t ldx,
+                            const int32_t* row_index, int32_t rows, int32_t D, const float* gamma,
+                            const float* mean, const float* rstd, const float* dx_res, float* dx_out,
+                            void* dx_out_f16, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                            float* ws, hipStream_t stream);
+int cclip_attention_fwd_f16(const cclip_attn_desc* d, hipStream_t stream);
+int cclip_attention_bwd_f16(const cclip_attn_desc* d, hipStream_t stream);
+int cclip_patchify_f16(const float* image, void* out_f16, int32_t B, int32_t R, int32_t P, hipStream_t stream);
+int cclip_colsum_f16(const void* in, int32_t in_is_f16, int64_t ld, int32_t R, int32_t C, float* out,
+                     int32_t accumulate, float* ws, hipStream_t stream);
+int cclip_xent_rows_f16(const float* logits, int64_t ld, int32_t R, int32_t C, const int32_t* labels,
+                        int32_t ignore_index, float grad_scale, float* loss_row, int32_t* pred,
+                        void* dlogits, int32_t dlogits_is_f16, int64_t ldd, float* rowdot, hipStream_t stream);
+int cclip_adamw_step_f16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                         int32_t correct_bias, float grad_scale, int32_t mode, void* f16_shadow,
+                         hipStream_t stream);
+int cclip_cast_f32_to_f16(const float* in, void* out, int64_t n, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

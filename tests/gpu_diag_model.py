@@ -25,18 +25,18 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item(), ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def run(fix):
+def run(fix, dtype=torch.bfloat16):
     g = torch.load(os.path.join(ROOT, "tests", "golden", fix), weights_only=True)
     geo = MODELS[g["model"]]
     sd = init_state_dict(geo, g["seed"])
-    model = clip.build_model(sd).cuda()
+    model = clip.build_model(sd, dtype).cuda()
     img = synthetic_images(g["n"], geo, g["seed"] + 1).cuda()
     txt = g["text"].cuda()
     with torch.no_grad():
         fi, ft = model.encode_image(img), model.encode_text(txt)
         li, lt = model(img, txt)
     torch.cuda.synchronize()
-    print(f"== {fix} ({g['model']}, n={g['n']})")
+    print(f"== {fix} ({g['model']}, n={g['n']}) compute dtype {dtype}")
     print("  image_features rel(l2,max):", rel(fi, g["image_features"]))
     print("  text_features  rel(l2,max):", rel(ft, g["text_features"]))
     d = (li.cpu() - g["logits_per_image"]).abs()
@@ -81,9 +81,9 @@ def run(fix):
 
 if __name__ == "__main__":
     t0 = time.time()
-    for f in ("clip_test_tiny.pt", "clip_test_small.pt", "clip_vit_b32.pt"):
+    for f, dt in [(f, dt) for dt in (torch.float16, torch.bfloat16) for f in ("clip_test_tiny.pt", "clip_test_small.pt", "clip_vit_b32.pt")]:
         try:
-            run(f)
+            run(f, dt)
         except Exception as e:  # keep going: one run should tell as much as possible
             import traceback
             traceback.print_exc()

@@ -49,6 +49,17 @@ def test_caption_forward_logits_and_mapper():
     assert torch.equal(lg2, out.logits)
 
 
+def test_caption_fp16_mode_is_tighter():
+    g, geo, model, tokens, mask, prefix, attribute = _setup()
+    model.half()
+    loss = model.caption_loss(tokens, prefix, attribute, mask)
+    loss.backward()
+    assert abs(loss.item() - g["loss"].item()) < 6e-4
+    params = dict(model.named_parameters())
+    for k, ref in g["grads"].items():
+        assert rel(sample(params[k].grad), ref) < 1e-2, (k, rel(sample(params[k].grad), ref))
+
+
 def test_caption_loss_and_grads_fused():
     g, geo, model, tokens, mask, prefix, attribute = _setup()
     loss = model.caption_loss(tokens, prefix, attribute, mask)
