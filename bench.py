@@ -112,8 +112,10 @@ def main():
     from clip.weights import MODELS, init_state_dict, synthetic_text
     from cclip_hip import ops
 
-    rank, world, local = parallel.init_distributed()
+    rank, world, local = parallel.init_distributed(os.environ.get("CCLIP_DIST_BACKEND"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if "CCLIP_FORCE_DEVICE" in os.environ:      # rehearsal of the N>1 path on a one-GPU box (gloo backend)
+        local = int(os.environ["CCLIP_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     geo = MODELS[args.model]
@@ -170,12 +172,13 @@ def main():
 
     # ---- roofline leg: same steps again with every GEMM launch bracketed by HIP events ----
     roof = None
+    nprof = min(2, args.steps)
     if rank == 0:
         ops.GEMM_EVENTS = []
-        nprof = min(2, args.steps)
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(nprof):          # every rank steps (the step contains collectives); only rank 0 records events
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         ev = ops.GEMM_EVENTS
         ops.GEMM_EVENTS = None
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)

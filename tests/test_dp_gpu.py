@@ -1,0 +1,72 @@
+"""GPU, 2 ranks sharing the one MI355X (gloo moves the bytes; RCCL refuses two ranks on one device): the full
+data-parallel step - HIP towers, all-gather of normalised features, per-rank logits row blocks, reduce-scatter of the
+cross-rank feature gradients, SUM all-reduce of the flat gradient arena - must reproduce the single-process step on
+the concatenated batch (loss, accuracy count, every parameter gradient)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NLOC, WORLD, MODEL, SEED = 6, 2, "test-small", 31
+
+
+def _batch():
+    from clip.weights import MODELS, synthetic_images, synthetic_text
+    geo = MODELS[MODEL]
+    return synthetic_images(NLOC * WORLD, geo, SEED + 1), synthetic_text(NLOC * WORLD, geo, SEED + 2)
+
+
+def _worker(rank, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "construction-clip_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK="0")
+    import clip
+    from clip import parallel
+    from clip.weights import MODELS, init_state_dict
+    parallel.init_distributed("gloo")
+    torch.cuda.set_device(0)
+    model = clip.build_model(init_state_dict(MODELS[MODEL], SEED)).cuda().train()
+    parallel.broadcast_parameters(model)
+    img, txt = _batch()
+    sl = slice(rank * NLOC, (rank + 1) * NLOC)
+    fi, ft = model.encode_image(img[sl].cuda()), model.encode_text(txt[sl].cuda())
+    loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale)
+    loss.backward()
+    parallel.allreduce_gradients(model, max_bucket_elems=1 << 18)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save(dict(loss=loss.detach().cpu(), stats=stats.cpu(),
+                        grads={k: v.grad.detach().cpu().clone() for k, v in model.named_parameters()}),
+                   os.path.join(out_dir, "dp.pt"))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_equals_single_process(tmp_path):
+    import clip
+    from clip.weights import MODELS, init_state_dict
+    port = 29200 + (os.getpid() % 500)
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    dp = torch.load(os.path.join(tmp_path, "dp.pt"), weights_only=True)
+    model = clip.build_model(init_state_dict(MODELS[MODEL], SEED)).cuda().train()
+    img, txt = _batch()
+    loss, stats = clip.contrastive_loss(model.encode_image(img.cuda()), model.encode_text(txt.cuda()), model.logit_scale)
+    loss.backward()
+    assert abs(loss.item() - dp["loss"].item()) < 1e-5
+    assert int(stats[1].item()) == int(dp["stats"][1].item())
+    worst = 0.0
+    for k, v in model.named_parameters():
+        ref, got = v.grad.detach().cpu(), dp["grads"][k]
+        r = ((got - ref).norm() / ref.norm().clamp_min(1e-20)).item()
+        worst = max(worst, r)
+        # the fp32 feature gradients differ in the last bits (summation order), which flips a few bf16 roundings of the
+        # gradient stream's 16-bit copies: measured worst 2.1e-3
+        assert r < 1e-2, (k, r)
+    print("worst relative grad difference DP vs single:", worst)
