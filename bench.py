@@ -189,8 +189,18 @@ def main():
             t, fl, n = by.get(k, (0.0, 0.0, 0))
             by[k] = (t + e0.elapsed_time(e1), fl + f, n + 1)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="gemm_bf16_128<*> (all layouts)", achieved=round(ach, 1),
-                    peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(ach * 1e12 / PEAK_BF16, 4), traffic=None,
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_train_bs1024_hbm_traffic_pmc.json")
+        if os.path.exists(tp) and args.mode == "train" and B == 1024 and args.dtype == "bf16":
+            # PMC counters cannot be read from inside the process: this is the committed rocprofv3 --pmc summary of the
+            # same command (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE), bytes per GEMM launch
+            gf = json.load(open(tp))["gemm_family"]
+            traffic = round((gf["fetch_mb_per_launch_corrected"] + gf["write_mb_per_launch"]) * 1e6)
+            traffic_src = "profiles/r01_train_bs1024_hbm_traffic_pmc.json"
+        roof = dict(bound="mfma", kernel="gemm_bf16_kernel<*> (all layouts and tile configs)", achieved=round(ach, 1),
+                    peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(ach * 1e12 / PEAK_BF16, 4), traffic=traffic,
+                    traffic_unit="HBM-side bytes per launch (PMC, includes Infinity-Cache hits)", traffic_source=traffic_src,
+                    flops_per_launch=round(tot_fl / max(len(ev), 1)),
                     launches_per_step=len(ev) // nprof, gemm_ms_per_step=round(tot_ms / nprof, 3),
                     by_layout={k: dict(tflops=round(fl / (t * 1e-3) / 1e12, 1), ms_per_step=round(t / nprof, 3), launches=n // nprof)
                                for k, (t, fl, n) in by.items()})

@@ -209,21 +209,30 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     if (c < C) part[(long)rs * C + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
 }
-// out[c] (+)= sum_rs part[rs][c]; block = 32 columns x 8 row groups, fixed order
+// out[c] (+)= sum_rs part[rs][c]; block = 16 columns x 16 row groups (4 independent partial sums per thread keep
+// several loads in flight), fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nrs, int C,
                                                            float* __restrict__ out, int accumulate) {
-  __shared__ float red[8][32];
-  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + c;
-  float s = 0.f;
-  if (col < C)
-    for (int r = rg; r < nrs; r += 8) s += part[(long)r * C + col];
-  red[rg][c] = s;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < C) {
+    int r = rg;
+    for (; r + 48 < nrs; r += 64) {
+      s0 += part[(long)r * C + col];
+      s1 += part[(long)(r + 16) * C + col];
+      s2 += part[(long)(r + 32) * C + col];
+      s3 += part[(long)(r + 48) * C + col];
+    }
+    for (; r < nrs; r += 16) s0 += part[(long)r * C + col];
+  }
+  red[rg][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && col < C) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][c];
+    for (int r = 0; r < 16; ++r) t += red[r][c];
     out[col] = accumulate ? out[col] + t : t;
   }
 }
@@ -318,6 +327,6 @@ extern "C" int CCLIP_FN(cclip_colsum)(const void* in, int32_t in_is_bf16, int64_
   else hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, stream, (const float*)in, (long)ld, R, C, ws);
   int st = cclip_launch_status();
   if (st != CCLIP_OK) return st;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, ws, nrs, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, ws, nrs, C, out, accumulate);
   return cclip_launch_status();
 }

@@ -158,25 +158,34 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_bwd_kernel(const DY* __restr
   }
 }
 
-// column sums of part[nblk][2][D] -> dgamma[D], dbeta[D].  Block = 32 columns x 8 row groups; fixed
-// summation order -> deterministic.
+// column sums of part[nblk][2][D] -> dgamma[D], dbeta[D].  Block = 16 columns x 16 row groups, 4 loads in
+// flight per thread; fixed summation order -> deterministic.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int accumulate) {
-  __shared__ float red[8][32];
-  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + c;                 // column in [0, 2D)
-  float s = 0.f;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + c;                 // column in [0, 2D)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < 2 * D) {
     const int which = i / D, col = i % D;
-    for (int b = rg; b < nblk; b += 8) s += part[((long)b * 2 + which) * D + col];
+    const float* base = part + (long)which * D + col;
+    const long st = 2L * D;
+    int b = rg;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += base[(long)b * st];
+      s1 += base[(long)(b + 16) * st];
+      s2 += base[(long)(b + 32) * st];
+      s3 += base[(long)(b + 48) * st];
+    }
+    for (; b < nblk; b += 16) s0 += base[(long)b * st];
   }
-  red[rg][c] = s;
+  red[rg][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && i < 2 * D) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][c];
+    for (int r = 0; r < 16; ++r) t += red[r][c];
     const int which = i / D, col = i % D;
     float* dst = which == 0 ? dgamma : dbeta;
     dst[col] = accumulate ? dst[col] + t : t;
@@ -228,6 +237,6 @@ extern "C" int CCLIP_FN(cclip_layernorm_bwd)(const void* dy, int32_t dy_is_bf16,
 #undef LNB
   int st = cclip_launch_status();
   if (st != CCLIP_OK || !dgamma) return st;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, stream, ws, nblk, D, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, stream, ws, nblk, D, dgamma, dbeta, accumulate);
   return cclip_launch_status();
 }
