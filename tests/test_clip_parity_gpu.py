@@ -222,3 +222,26 @@ def test_shape_errors_raise():
         model.encode_text(txt[:, :8])
     with pytest.raises(RuntimeError):
         model.encode_image(img.cpu())
+
+
+def test_batched_zero_shot_and_embedding_extraction_match_per_image_calls():
+    """parse_coco.py:40-56 run per image at batch 1 == the batched extractor with prompt features encoded once."""
+    from clip.data import ZeroShotClassifier
+    from clip_caption.data import VIOLATION_TYPES, extract_embeddings
+    g, model, img, txt = _setup("clip_test_small.pt", torch.float16)
+    prompts9, prompts2 = txt[:9], txt[:2]
+    tok = lambda texts: prompts2 if len(texts) == 2 else prompts9      # stands in for clip.tokenize (no BPE vocab offline)
+    anns = [{"id": i, "caption": "c", "violation_list": "v"} for i in range(img.shape[0])]
+    emb, caps = extract_embeddings(model, anns, lambda a: img[a["id"]].cpu(), tok, batch_size=4)
+    assert emb.shape == (img.shape[0], g["image_features"].shape[1]) and [c["clip_embedding"] for c in caps] == list(range(len(anns)))
+    with torch.no_grad():
+        for i in range(img.shape[0]):
+            one = img[i:i + 1]
+            prefix = model.encode_image(one)                                   # parse_coco.py:43
+            assert torch.equal(prefix.cpu(), emb[i:i + 1])                     # batch independence -> bit-exact
+            li, _ = model(one, prompts9)                                       # parse_coco.py:50
+            idx = int(li.softmax(dim=-1).argmax(dim=1)[0])
+            assert caps[i]["attribute"].split(" ")[1] == VIOLATION_TYPES[idx]
+    z = ZeroShotClassifier(model, prompts9, VIOLATION_TYPES)
+    sim, idx, labels = z(img)
+    assert torch.equal(idx[:1].cpu(), g["zs9_idx"]) and (sim[:1].cpu() - g["zs9_sim"]).abs().max() < 2e-3
