@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="ViT-B/32")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit MFMA operand type")
+    ap.add_argument("--tower-streams", type=int, default=int(os.environ.get("CCLIP_TOWER_STREAMS", "2")),
+                    help="2 = run the image and text towers (forward and backward) on two HIP streams")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -131,14 +133,19 @@ def main():
     text = synthetic_text(B, geo, 567 + rank).to(dev)
     group = None
 
+    os.environ["CCLIP_TOWER_STREAMS"] = str(args.tower_streams)
+
+    def encode_both():
+        return model.encode_image_text(image, text)
+
     def step():
         if args.mode == "fwd":
             with torch.no_grad():
-                fi, ft = model.encode_image(image), model.encode_text(text)
+                fi, ft = encode_both()
                 loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale, group)
             return stats
         opt.zero_grad()
-        fi, ft = model.encode_image(image), model.encode_text(text)
+        fi, ft = encode_both()
         loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale, group)
         loss.backward()
         parallel.allreduce_gradients(model, group)
@@ -175,9 +182,11 @@ def main():
     nprof = min(2, args.steps)
     if rank == 0:
         ops.GEMM_EVENTS = []
+    os.environ["CCLIP_TOWER_STREAMS"] = "1"   # kernel durations are measured with the launches serialised on one stream
     for _ in range(nprof):          # every rank steps (the step contains collectives); only rank 0 records events
         step()
     torch.cuda.synchronize()
+    os.environ["CCLIP_TOWER_STREAMS"] = str(args.tower_streams)
     if rank == 0:
         ev = ops.GEMM_EVENTS
         ops.GEMM_EVENTS = None
