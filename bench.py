@@ -183,6 +183,7 @@ def main():
     if rank == 0:
         ops.GEMM_EVENTS = []
     os.environ["CCLIP_TOWER_STREAMS"] = "1"   # kernel durations are measured with the launches serialised on one stream
+    os.environ["CCLIP_WGRAD_STREAM"] = "0"
     for _ in range(nprof):          # every rank steps (the step contains collectives); only rank 0 records events
         step()
     torch.cuda.synchronize()

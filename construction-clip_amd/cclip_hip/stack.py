@@ -150,34 +150,68 @@ class BlockStack:
         return x
 
     # ------------------------------------------------------------------ backward
-    def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool):
+    def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool, scratch=None):
         """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out]."""
         a, b = (dy, xin) if self.geo.linear_layout else (xin, dy)
         n_out, k_in = gw.shape
         ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
-                      split_candidates=wgrad_candidates(n_out, k_in, M), scratch=self.scratch.floats)
+                      split_candidates=wgrad_candidates(n_out, k_in, M), scratch=(scratch or self.scratch).floats)
 
-    def _bgrad(self, dy: torch.Tensor, gb: torch.Tensor, M: int, acc: bool):
+    def _bgrad(self, dy: torch.Tensor, gb: torch.Tensor, M: int, acc: bool, scratch=None):
         C = gb.numel()
-        ws = self.scratch.floats(ops.colsum_ws_floats(M, C))
+        ws = (scratch or self.scratch).floats(ops.colsum_ws_floats(M, C))
         ops.colsum(dy, gb, ws, R=M, C=C, ld=dy.stride(0), accumulate=acc)
 
-    def backward(self, dx: torch.Tensor, dxb: torch.Tensor, saved: dict, acc: Dict[int, bool]):
-        """dx (fp32) / dxb (bf16 copy): gradient w.r.t. the stack output, [B*T, D]; both are updated
-        in place layer by layer and on return hold the gradient w.r.t. the stack input.
-        acc[id(grad_tensor)] says whether that grad buffer already holds a gradient to add to."""
+    def backward(self, dx: torch.Tensor, dxb: torch.Tensor, saved: dict, acc: Dict[int, bool]) -> torch.Tensor:
+        """dx (fp32) / dxb (16-bit copy): gradient w.r.t. the stack output, [B*T, D].  dx is updated in place layer by
+        layer and on return holds the gradient w.r.t. the stack input; the matching 16-bit copy is RETURNED.
+        acc[id(grad_tensor)] says whether that grad buffer already holds a gradient to add to.
+
+        The dgrad chain (GEMM -> LN / attention backward -> GEMM ...) is latency-critical and half memory-bound; the
+        weight/bias gradients hang off it as leaves.  They are therefore issued on a SIDE stream (every dY / dX
+        copy gets its own buffer - 288 GB makes that free - so nothing is overwritten under a running wgrad): the
+        long MFMA-bound wgrad launches fill the CUs while the chain's LN / attention / epilogue phases wait on HBM.
+        CCLIP_WGRAD_STREAM=0 keeps everything on one stream."""
+        import os
         geo = self.geo
         D, H = geo.width, geo.heads
         B, T = saved["B"], saved["T"]
         M = B * T
+        L = len(self.blocks)
         dev = dx.device
         kc = geo.linear_layout
         dact = _DACT[geo.act]
         bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
-        tmp = torch.empty(M, 8 * D, device=dev, dtype=self.dtype)      # dh | dqkv | dxn / da
-        dh, dqkv, dsm = tmp[:, 0:4 * D], tmp[:, 4 * D:7 * D], tmp[:, 7 * D:8 * D]
+        trainable = any(b.grads is not None for b in self.blocks)
+        side = None
+        if trainable and os.environ.get("CCLIP_WGRAD_STREAM", "1") == "1" and dev.type == "cuda":
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=dev)
+                self._side_scratch = Scratch(dev)
+            side = self._side
+        cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+        if side is not None:
+            side.wait_stream(cur)
+            dh_all = torch.empty(L, M, 4 * D, device=dev, dtype=self.dtype)
+            dqkv_all = torch.empty(L, M, 3 * D, device=dev, dtype=self.dtype)
+            dxb_all = torch.empty(2 * L, M, D, device=dev, dtype=self.dtype)
+            tmp = torch.empty(M, D, device=dev, dtype=self.dtype)
+        else:
+            tmp8 = torch.empty(M, 8 * D, device=dev, dtype=self.dtype)      # dh | dqkv | dxn / da
         ln_ws = self.scratch  # partial sums live in scratch; sized per call
-        for l in range(len(self.blocks) - 1, -1, -1):
+
+        def leaf(fn):
+            """run a parameter-gradient launch group where it belongs: after what the main stream has produced so far"""
+            if side is None:
+                fn(self.scratch)
+                return
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn(self._side_scratch)
+
+        for l in range(L - 1, -1, -1):
             w = self.blocks[l]
             gr = w.grads
             row = bf[l]
@@ -185,37 +219,55 @@ class BlockStack:
             xn2, h, g = row[:, 5 * D:6 * D], row[:, 6 * D:10 * D], row[:, 10 * D:14 * D]
             x_in, x_mid = xs[l, 0], xs[l, 1]
             m1, r1, m2, r2 = st[l, 0], st[l, 1], st[l, 2], st[l, 3]
+            if side is not None:
+                dh, dqkv, dsm = dh_all[l], dqkv_all[l], tmp
+                dxb_mid, dxb_in = dxb_all[2 * l + 1], dxb_all[2 * l]
+            else:
+                dh, dqkv, dsm = tmp8[:, 0:4 * D], tmp8[:, 4 * D:7 * D], tmp8[:, 7 * D:8 * D]
+                dxb_mid = dxb_in = dxb
 
-            def A(name):
-                t = gr[name]
-                return acc.get(id(t), False)
+            def A(name, gr=gr):
+                return acc.get(id(gr[name]), False)
 
             # ---- MLP branch ----
             if gr is not None:
-                self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj"))
-                self._bgrad(dxb, gr["b_proj"], M, A("b_proj"))
+                def f1(sc, dxb=dxb, g=g, gr=gr):
+                    self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc)
+                    self._bgrad(dxb, gr["b_proj"], M, A("b_proj", gr), sc)
+                leaf(f1)
             ops.gemm_bf16(dxb, w.w_proj, b_kcontig=not kc, act=dact, aux=h, out_bf16=dh, M=M)
             if gr is not None:
-                self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc"))
-                self._bgrad(dh, gr["b_fc"], M, A("b_fc"))
+                def f2(sc, dh=dh, xn2=xn2, gr=gr):
+                    self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc)
+                    self._bgrad(dh, gr["b_fc"], M, A("b_fc", gr), sc)
+                leaf(f2)
             ops.gemm_bf16(dh, w.w_fc, b_kcontig=not kc, out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
-            ops.layernorm_bwd(dsm, x_mid, w.ln2_w, m2, r2, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb,
+            ops.layernorm_bwd(dsm, x_mid, w.ln2_w, m2, r2, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_mid,
                               dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
                               accumulate=A("ln2_w") if gr is not None else False, ws=ws)
+            dxb = dxb_mid
             # ---- attention branch ----
             if gr is not None:
-                self._wgrad(dxb, a, gr["w_o"], M, A("w_o"))
-                self._bgrad(dxb, gr["b_o"], M, A("b_o"))
+                def f3(sc, dxb=dxb, a=a, gr=gr):
+                    self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc)
+                    self._bgrad(dxb, gr["b_o"], M, A("b_o", gr), sc)
+                leaf(f3)
             ops.gemm_bf16(dxb, w.w_o, b_kcontig=not kc, out_bf16=dsm, M=M)
             ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
                               dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
                               key_keep=saved["key_keep"])
             if gr is not None:
-                self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv"))
-                self._bgrad(dqkv, gr["b_qkv"], M, A("b_qkv"))
+                def f4(sc, dqkv=dqkv, xn1=xn1, gr=gr):
+                    self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc)
+                    self._bgrad(dqkv, gr["b_qkv"], M, A("b_qkv", gr), sc)
+                leaf(f4)
             ops.gemm_bf16(dqkv, w.w_qkv, b_kcontig=not kc, out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
-            ops.layernorm_bwd(dsm, x_in, w.ln1_w, m1, r1, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb,
+            ops.layernorm_bwd(dsm, x_in, w.ln1_w, m1, r1, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_in,
                               dgamma=gr["ln1_w"] if gr is not None else None, dbeta=gr["ln1_b"] if gr is not None else None,
                               accumulate=A("ln1_w") if gr is not None else False, ws=ws)
+            dxb = dxb_in
+        if side is not None:
+            cur.wait_stream(side)        # every parameter gradient is complete before anyone downstream looks at it
+        return dxb

@@ -264,7 +264,7 @@ class CLIP(nn.Module):
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["visual.ln_post.weight"],
                           dbeta=g["visual.ln_post.bias"], accumulate=A("visual.ln_post.weight"),
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
-        st.backward(dx, dxb, c["saved"], acc)
+        dxb = st.backward(dx, dxb, c["saved"], acc)
         ops.layernorm_bwd(dx, c["x0"], p["visual.ln_pre.weight"].data, c["st0"][0], c["st0"][1], rows=M, dx_out=dx,
                           dx_out_bf16=dxb, dgamma=g["visual.ln_pre.weight"], dbeta=g["visual.ln_pre.bias"],
                           accumulate=A("visual.ln_pre.weight"), ws=sc.floats(ops.layernorm_bwd_ws_floats(M, D)))
@@ -325,7 +325,7 @@ class CLIP(nn.Module):
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["ln_final.weight"],
                           dbeta=g["ln_final.bias"], accumulate=A("ln_final.weight"),
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
-        st.backward(dx, dxb, c["saved"], acc)
+        dxb = st.backward(dx, dxb, c["saved"], acc)
         ops.colsum(dx, g["positional_embedding"], sc.floats(ops.colsum_ws_floats(B, L * D)), R=B, C=L * D, ld=L * D,
                    accumulate=A("positional_embedding"))
         if not A("token_embedding.weight"):

@@ -391,7 +391,7 @@ class ClipCaptionModel(nn.Module):
                           dgamma=None if frozen else g[lnf_w], dbeta=None if frozen else g[lnf_b],
                           accumulate=False if frozen else A(lnf_w),
                           ws=None if frozen else sc.floats(ops.layernorm_bwd_ws_floats(R, D)))
-        stack.backward(dx, dxb, c["saved"], acc)
+        dxb = stack.backward(dx, dxb, c["saved"], acc)
         if not frozen:
             # x = [prefix_proj | wte[ids]] + wpe[s]
             wpe = "model.transformer.wpe.weight"
