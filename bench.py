@@ -50,19 +50,19 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(mode: str, budget_s: float = 20.0):
-    """Oracle step on the host cores: bounded sample (batch 8), median of a few iterations."""
+def cpu_baseline(mode: str, budget_s: float = 12.0):
+    """Oracle step on the host cores: bounded sample (batch 32, ~10-20 s of CPU work), median iteration."""
     from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
     from oracle import clip_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     geo = MODELS["ViT-B/32"]
-    bs = 8
+    bs = 32
     sd = init_state_dict(geo, 567)
     img, txt = synthetic_images(bs, geo, 568), synthetic_text(bs, geo, 569)
     times = []
     t_all = time.time()
-    for it in range(4):
+    for it in range(12):
         t0 = time.time()
         if mode == "train":
             sdg = {k: v.requires_grad_(True) for k, v in sd.items()}
@@ -76,7 +76,7 @@ def cpu_baseline(mode: str, budget_s: float = 20.0):
                 O.clip_forward(sd, img, txt)
         times.append(time.time() - t0)
         log(f"cpu baseline iteration {it}: {times[-1]:.2f}s")
-        if time.time() - t_all > budget_s and it >= 1:
+        if time.time() - t_all > budget_s and it >= 2:
             break
     t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
     return dict(value=bs / t, unit="pairs/s", cores=cores, kind="port",
