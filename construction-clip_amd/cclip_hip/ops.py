@@ -254,7 +254,7 @@ class AttnDesc(ctypes.Structure):
     ]
 
 
-def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale):
+def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale, head_dim=64):
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
         _req16(t, n)
         assert t.stride(-1) == 1
@@ -264,8 +264,8 @@ def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale):
     d.o, d.ldo = o.data_ptr(), o.stride(-2)
     d.lse = 0 if lse is None else lse.data_ptr()
     d.key_keep = 0 if key_keep is None else key_keep.data_ptr()
-    d.B, d.T, d.H, d.head_dim, d.causal = B, T, H, 64, int(causal)
-    d.scale = 0.125 if scale is None else scale
+    d.B, d.T, d.H, d.head_dim, d.causal = B, T, H, head_dim, int(causal)
+    d.scale = head_dim ** -0.5 if scale is None else scale
     return d
 
 
@@ -282,6 +282,20 @@ def attention_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H: int, 
     d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     d.lddq, d.lddk, d.lddv = dq.stride(-2), dk.stride(-2), dv.stride(-2)
     check(_fn("cclip_attention_bwd", q, k, v, o, dout, dq, dk, dv)(ctypes.byref(d), _stream()), "cclip_attention_bwd")
+
+
+def attention_small_fwd(q, k, v, o, *, B: int, T: int, H: int, head_dim: int, lse=None, scale=None) -> None:
+    """Generic-head_dim unmasked attention (TransformerMapper): same tensor conventions as attention_fwd."""
+    d = _attn_desc(q, k, v, o, lse, B, T, H, False, None, scale, head_dim)
+    check(_fn("cclip_attention_small_fwd", q, k, v, o)(ctypes.byref(d), _stream()), "cclip_attention_small_fwd")
+
+
+def attention_small_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H: int, head_dim: int, scale=None) -> None:
+    d = _attn_desc(q, k, v, o, lse, B, T, H, False, None, scale, head_dim)
+    d.dout, d.lddo = dout.data_ptr(), dout.stride(-2)
+    d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.lddq, d.lddk, d.lddv = dq.stride(-2), dk.stride(-2), dv.stride(-2)
+    check(_fn("cclip_attention_small_bwd", q, k, v, o, dout, dq, dk, dv)(ctypes.byref(d), _stream()), "cclip_attention_small_bwd")
 
 
 # --------------------------------------------------------------------------------------------
@@ -331,6 +345,8 @@ def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None,
 
 
 def caption_embed(prefix_proj, ids_i32, wte, wpe, x, *, B: int, P: int, Lt: int) -> None:
+    _req(prefix_proj, torch.float32, "prefix_proj")
+    assert prefix_proj.is_contiguous() and prefix_proj.numel() == B * P * wte.shape[1], "prefix_proj must be dense [B, P*D]"
     check(lib.cclip_caption_embed(_p(prefix_proj), _p(ids_i32), _p(wte), _p(wpe), c_int(B), c_int(P), c_int(Lt),
                                   c_int(wte.shape[1]), c_int(wte.shape[0]), _p(x), _stream()), "cclip_caption_embed")
 

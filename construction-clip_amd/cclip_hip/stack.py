@@ -30,7 +30,7 @@ from . import ops
 class BlockWeights:
     """bf16 compute copies of the matrices + fp32 vectors of one block, and where their grads go."""
     ln1_w: torch.Tensor; ln1_b: torch.Tensor
-    w_qkv: torch.Tensor; b_qkv: torch.Tensor
+    w_qkv: torch.Tensor; b_qkv: Optional[torch.Tensor]
     w_o: torch.Tensor; b_o: torch.Tensor
     ln2_w: torch.Tensor; ln2_b: torch.Tensor
     w_fc: torch.Tensor; b_fc: torch.Tensor
@@ -44,8 +44,10 @@ class StackGeometry:
     heads: int
     tokens: int            # sequence length T
     linear_layout: bool    # True: weights [out, in] (nn.Linear); False: [in, out] (GPT-2 Conv1D)
-    act: int               # ops.ACT_QUICKGELU / ops.ACT_GELU_NEW
+    act: int               # ops.ACT_QUICKGELU / ops.ACT_GELU_NEW / ops.ACT_RELU
     causal: bool
+    head_dim: int = 64     # 64 -> MFMA attention (attention.hip); anything else -> attention_small.hip (no mask)
+    hidden: int = 0        # MLP hidden size; 0 = 4 * width
 
 
 _DACT = {ops.ACT_QUICKGELU: ops.ACT_DQUICKGELU, ops.ACT_GELU_NEW: ops.ACT_DGELU_NEW, ops.ACT_RELU: ops.ACT_DRELU}
@@ -97,10 +99,11 @@ class BlockStack:
         """Activation store for one training forward.  The caller writes the stack input (fp32 [B*T, D])
         into saved["xs"][0, 0] and passes that view as `x`."""
         D, H = self.geo.width, self.geo.heads
+        Hd = self.geo.hidden or 4 * D
         T = T or self.geo.tokens
         M, L = B * T, len(self.blocks)
         return dict(T=T,
-            bf=torch.empty(L, M, 14 * D, device=device, dtype=self.dtype),   # xn1 | qkv | a | xn2 | h | g
+            bf=torch.empty(L, M, 6 * D + 2 * Hd, device=device, dtype=self.dtype),   # xn1 | qkv | a | xn2 | h | g
             xs=torch.empty(L, 2, M, D, device=device, dtype=torch.float32),      # x_in, x_mid
             st=torch.empty(L, 4, M, device=device, dtype=torch.float32),         # mean1 rstd1 mean2 rstd2
             lse=torch.empty(L, B, H, T, device=device, dtype=torch.float32),
@@ -112,6 +115,7 @@ class BlockStack:
         saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0]."""
         geo = self.geo
         D, H = geo.width, geo.heads
+        Hd = geo.hidden or 4 * D
         T = T or geo.tokens
         M = B * T
         L = len(self.blocks)
@@ -123,25 +127,30 @@ class BlockStack:
             bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
             saved["key_keep"] = key_keep
         else:
-            bf = torch.empty(M, 10 * D, device=dev, dtype=self.dtype)      # xn | qkv | a | - | g  (reused per layer)
+            bf = torch.empty(M, 6 * D + Hd, device=dev, dtype=self.dtype)  # xn | qkv | a | - | g  (reused per layer)
         for l, w in enumerate(self.blocks):
             if train:
                 row = bf[l]
                 xn1, qkv, a = row[:, 0:D], row[:, D:4 * D], row[:, 4 * D:5 * D]
-                xn2, h, g = row[:, 5 * D:6 * D], row[:, 6 * D:10 * D], row[:, 10 * D:14 * D]
+                xn2, h, g = row[:, 5 * D:6 * D], row[:, 6 * D:6 * D + Hd], row[:, 6 * D + Hd:6 * D + 2 * Hd]
                 x_in, x_mid = xs[l, 0], xs[l, 1]
                 x_out = xs[l + 1, 0] if l + 1 < L else saved["out"]
                 m1, r1, m2, r2 = st[l, 0], st[l, 1], st[l, 2], st[l, 3]
                 lse_l = lse[l]
             else:
-                xn1, qkv, a, g = bf[:, 0:D], bf[:, D:4 * D], bf[:, 4 * D:5 * D], bf[:, 6 * D:10 * D]
+                xn1, qkv, a, g = bf[:, 0:D], bf[:, D:4 * D], bf[:, 4 * D:5 * D], bf[:, 6 * D:6 * D + Hd]
                 xn2, h = xn1, None
                 x_in = x_mid = x_out = x
                 m1 = r1 = m2 = r2 = lse_l = None
             ops.layernorm_fwd(x_in, w.ln1_w, w.ln1_b, rows=M, out_bf16=xn1, mean=m1, rstd=r1)
             ops.gemm_bf16(xn1, w.w_qkv, b_kcontig=kc, bias=w.b_qkv, out_bf16=qkv, M=M)
-            ops.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H, causal=geo.causal,
-                              key_keep=key_keep, lse=lse_l)
+            if geo.head_dim == 64:
+                ops.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H, causal=geo.causal,
+                                  key_keep=key_keep, lse=lse_l)
+            else:
+                assert not geo.causal and key_keep is None
+                ops.attention_small_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H,
+                                        head_dim=geo.head_dim, lse=lse_l)
             ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in, out_f32=x_mid, M=M)
             ops.layernorm_fwd(x_mid, w.ln2_w, w.ln2_b, rows=M, out_bf16=xn2, mean=m2, rstd=r2)
             ops.gemm_bf16(xn2, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, out_pre=h, M=M)
@@ -175,6 +184,7 @@ class BlockStack:
         import os
         geo = self.geo
         D, H = geo.width, geo.heads
+        Hd = geo.hidden or 4 * D
         B, T = saved["B"], saved["T"]
         M = B * T
         L = len(self.blocks)
@@ -192,12 +202,12 @@ class BlockStack:
         cur = torch.cuda.current_stream() if dev.type == "cuda" else None
         if side is not None:
             side.wait_stream(cur)
-            dh_all = torch.empty(L, M, 4 * D, device=dev, dtype=self.dtype)
+            dh_all = torch.empty(L, M, Hd, device=dev, dtype=self.dtype)
             dqkv_all = torch.empty(L, M, 3 * D, device=dev, dtype=self.dtype)
             dxb_all = torch.empty(2 * L, M, D, device=dev, dtype=self.dtype)
             tmp = torch.empty(M, D, device=dev, dtype=self.dtype)
         else:
-            tmp8 = torch.empty(M, 8 * D, device=dev, dtype=self.dtype)      # dh | dqkv | dxn / da
+            tmp8 = torch.empty(M, 4 * D + Hd, device=dev, dtype=self.dtype)      # dh | dqkv | dxn / da
         ln_ws = self.scratch  # partial sums live in scratch; sized per call
 
         def leaf(fn):
@@ -216,14 +226,14 @@ class BlockStack:
             gr = w.grads
             row = bf[l]
             xn1, qkv, a = row[:, 0:D], row[:, D:4 * D], row[:, 4 * D:5 * D]
-            xn2, h, g = row[:, 5 * D:6 * D], row[:, 6 * D:10 * D], row[:, 10 * D:14 * D]
+            xn2, h, g = row[:, 5 * D:6 * D], row[:, 6 * D:6 * D + Hd], row[:, 6 * D + Hd:6 * D + 2 * Hd]
             x_in, x_mid = xs[l, 0], xs[l, 1]
             m1, r1, m2, r2 = st[l, 0], st[l, 1], st[l, 2], st[l, 3]
             if side is not None:
                 dh, dqkv, dsm = dh_all[l], dqkv_all[l], tmp
                 dxb_mid, dxb_in = dxb_all[2 * l + 1], dxb_all[2 * l]
             else:
-                dh, dqkv, dsm = tmp8[:, 0:4 * D], tmp8[:, 4 * D:7 * D], tmp8[:, 7 * D:8 * D]
+                dh, dqkv, dsm = tmp8[:, 0:Hd], tmp8[:, Hd:Hd + 3 * D], tmp8[:, Hd + 3 * D:Hd + 4 * D]
                 dxb_mid = dxb_in = dxb
 
             def A(name, gr=gr):
@@ -254,13 +264,18 @@ class BlockStack:
                     self._bgrad(dxb, gr["b_o"], M, A("b_o", gr), sc)
                 leaf(f3)
             ops.gemm_bf16(dxb, w.w_o, b_kcontig=not kc, out_bf16=dsm, M=M)
-            ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
-                              dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
-                              key_keep=saved["key_keep"])
+            if geo.head_dim == 64:
+                ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
+                                  dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
+                                  key_keep=saved["key_keep"])
+            else:
+                ops.attention_small_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
+                                        dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, head_dim=geo.head_dim)
             if gr is not None:
                 def f4(sc, dqkv=dqkv, xn1=xn1, gr=gr):
                     self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc)
-                    self._bgrad(dqkv, gr["b_qkv"], M, A("b_qkv", gr), sc)
+                    if gr.get("b_qkv") is not None:          # TransformerMapper's q / kv projections have no bias
+                        self._bgrad(dqkv, gr["b_qkv"], M, A("b_qkv", gr), sc)
                 leaf(f4)
             ops.gemm_bf16(dqkv, w.w_qkv, b_kcontig=not kc, out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None

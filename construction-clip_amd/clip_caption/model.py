@@ -13,7 +13,8 @@ plus `caption_loss()` - the fused form of train.py:354-357 that only ever materi
 
 Modules are parameter holders; arithmetic = cclip_hip launches (BlockStack with Conv1D layout + gelu_new +
 causal & key-padding attention).  fp32 masters in a flat arena, bf16 MFMA operands, fp32 residual stream.
-`TransformerMapper` (--mapping_type transformer, train.py:126-248, non-default) is not built yet.
+`TransformerMapper` (--mapping_type transformer, train.py:126-248) runs on the same BlockStack with head_dim 96
+(generic small-attention kernel), ReLU and MLP ratio 2.
 """
 from __future__ import annotations
 
@@ -30,7 +31,7 @@ from cclip_hip import ops
 from cclip_hip.arena import ParamArena
 from cclip_hip.stack import BlockStack, BlockWeights, Scratch, StackGeometry
 
-from .weights import GPT2_MODELS, CaptionGeometry, init_caption_state_dict
+from .weights import GPT2_MODELS, CaptionGeometry, init_caption_state_dict, init_transformer_mapper_state_dict
 
 
 class MappingType(Enum):
@@ -49,6 +50,15 @@ class _Affine(_Holder):       # LayerNorm / Linear / Conv1D parameter pair
         self.bias = nn.Parameter(torch.zeros(*b_shape))
 
 
+def _reset_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> None:
+    """nn.Linear.reset_parameters (what the reference's mappers get at construction): U(+-1/sqrt(fan_in)) for both."""
+    bound = weight.shape[1] ** -0.5
+    with torch.no_grad():
+        weight.uniform_(-bound, bound)
+        if bias is not None:
+            bias.uniform_(-bound, bound)
+
+
 class _Sequential(_Holder):
     """Key layout of nn.Sequential(Linear, Tanh, Linear): parameters live at .0 and .2"""
 
@@ -56,6 +66,7 @@ class _Sequential(_Holder):
         super().__init__()
         for i in range(len(sizes) - 1):
             self.add_module(str(2 * i), _Affine((sizes[i + 1], sizes[i]), (sizes[i + 1],)))
+            _reset_linear(getattr(self, str(2 * i)).weight, getattr(self, str(2 * i)).bias)
 
 
 class MLP(_Holder):
@@ -72,6 +83,71 @@ class MLP(_Holder):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._owner is None:
             raise RuntimeError("MLP must be used as ClipCaptionModel.clip_project")
+        return self._owner()._mapper_only(x)
+
+
+class _Weight(_Holder):      # bias-free Linear (TransformerMapper q / kv projections, train.py:188,192)
+    def __init__(self, n_out, n_in):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in))
+        _reset_linear(self.weight)
+
+
+class _MapperAttention(_Holder):
+    def __init__(self, d):
+        super().__init__()
+        # registration order matters: to_queries.weight and to_keys_values.weight are adjacent in the flat arena, so
+        # one packed [3D, D] view serves the fused q|k|v projection GEMM, its wgrad and its 16-bit shadow
+        self.to_queries = _Weight(d, d)
+        self.to_keys_values = _Weight(2 * d, d)
+        self.project = _Affine((d, d), (d,))
+        _reset_linear(self.project.weight, self.project.bias)
+
+
+class _MapperMLP(_Holder):
+    def __init__(self, d, h):
+        super().__init__()
+        self.fc1 = _Affine((h, d), (h,))
+        self.fc2 = _Affine((d, h), (d,))
+        _reset_linear(self.fc1.weight, self.fc1.bias)
+        _reset_linear(self.fc2.weight, self.fc2.bias)
+
+
+class _MapperLayer(_Holder):
+    def __init__(self, d, mlp_ratio=2.0):
+        super().__init__()
+        self.norm1 = _Affine((d,), (d,))
+        self.attn = _MapperAttention(d)
+        self.norm2 = _Affine((d,), (d,))
+        self.mlp = _MapperMLP(d, int(d * mlp_ratio))
+        with torch.no_grad():
+            self.norm1.weight.fill_(1.0)
+            self.norm2.weight.fill_(1.0)
+
+
+class _MapperTransformer(_Holder):
+    def __init__(self, d, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_MapperLayer(d) for _ in range(num_layers)])
+
+
+class TransformerMapper(_Holder):
+    """train.py:233-248: Linear(dim_clip, clip_length*D) -> cat(learned prefix_const) -> 8-head pre-LN Transformer
+    (mlp_ratio 2, ReLU, bias-free q/kv) -> the last prefix_length tokens."""
+
+    def __init__(self, dim_clip: int, dim_embedding: int, prefix_length: int, clip_length: int, num_layers: int = 8):
+        super().__init__()
+        self.clip_length, self.prefix_length, self.dim, self.num_heads = clip_length, prefix_length, dim_embedding, 8
+        self.sizes = (dim_clip,)
+        self.transformer = _MapperTransformer(dim_embedding, num_layers)
+        self.linear = _Affine((clip_length * dim_embedding, dim_clip), (clip_length * dim_embedding,))
+        _reset_linear(self.linear.weight, self.linear.bias)
+        self.prefix_const = nn.Parameter(torch.randn(prefix_length, dim_embedding))
+        self._owner = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._owner is None:
+            raise RuntimeError("TransformerMapper must be used as ClipCaptionModel.clip_project")
         return self._owner()._mapper_only(x)
 
 
@@ -181,10 +257,11 @@ class ClipCaptionModel(nn.Module):
         self.prefix_length = prefix_length
         self.model = GPT2LMHeadModel.from_pretrained(gpt2_type) if isinstance(gpt2_type, str) else GPT2LMHeadModel(gpt2_type)
         self.model_embedding_size = self.model.transformer.wte.weight.shape[1]
-        if mapping_type != MappingType.MLP:
-            raise NotImplementedError("mapping_type=transformer (train.py:126-248) is not built yet; the reference's default is mlp")
         d = self.model_embedding_size
-        self.clip_project = MLP((prefix_size, (d * prefix_length) // 2, d * prefix_length))
+        if mapping_type == MappingType.MLP:
+            self.clip_project = MLP((prefix_size, (d * prefix_length) // 2, d * prefix_length))
+        else:
+            self.clip_project = TransformerMapper(prefix_size, d, prefix_length, clip_length or prefix_length, num_layers)
         ref = weakref.ref(self)
         self.model._owner = ref
         self.clip_project._owner = ref
@@ -220,7 +297,11 @@ class ClipCaptionModel(nn.Module):
         geo = CaptionGeometry(vocab_size=geo.vocab_size, n_embd=geo.n_embd, n_layer=geo.n_layer, n_head=geo.n_head,
                               n_positions=geo.n_positions, prefix_length=self.prefix_length, attribute_length=0,
                               prefix_size=self.clip_project.sizes[0])
-        self.load_state_dict(init_caption_state_dict(geo, seed))
+        sd = init_caption_state_dict(geo, seed)
+        if isinstance(self.clip_project, TransformerMapper):
+            sd = {k: v for k, v in sd.items() if not k.startswith("clip_project.")}
+            sd.update(init_transformer_mapper_state_dict(geo, self.clip_project.clip_length, len(self.clip_project.transformer.layers), seed))
+        self.load_state_dict(sd)
         return self
 
     # ---- runtime ----
@@ -253,9 +334,84 @@ class ClipCaptionModel(nn.Module):
         self._arena = ar
         self._stack = BlockStack(StackGeometry(g.n_embd, g.n_head, 0, False, ops.ACT_GELU_NEW, True), blocks, Scratch(dev),
                                  self.compute_dtype)
+        self._mstack = None
+        if isinstance(self.clip_project, TransformerMapper):
+            mp = self.clip_project
+            D = mp.dim
+            mblocks = []
+            for i in range(len(mp.transformer.layers)):
+                q = f"clip_project.transformer.layers.{i}."
+                oq, okv = ar.offsets[q + "attn.to_queries.weight"], ar.offsets[q + "attn.to_keys_values.weight"]
+                assert okv == oq + D * D, "q and kv projection weights must be adjacent in the arena"
+                packed = lambda flat: flat[oq:oq + 3 * D * D].view(3 * D, D)
+                trainable = ar.params[q + "attn.to_queries.weight"].requires_grad
+                grads = None
+                if trainable:
+                    grads = dict(ln1_w=ar.g[q + "norm1.weight"], ln1_b=ar.g[q + "norm1.bias"], w_qkv=packed(ar.gflat), b_qkv=None,
+                                 w_o=ar.g[q + "attn.project.weight"], b_o=ar.g[q + "attn.project.bias"],
+                                 ln2_w=ar.g[q + "norm2.weight"], ln2_b=ar.g[q + "norm2.bias"],
+                                 w_fc=ar.g[q + "mlp.fc1.weight"], b_fc=ar.g[q + "mlp.fc1.bias"],
+                                 w_proj=ar.g[q + "mlp.fc2.weight"], b_proj=ar.g[q + "mlp.fc2.bias"])
+                P_ = ar.params
+                mblocks.append(BlockWeights(
+                    ln1_w=P_[q + "norm1.weight"].data, ln1_b=P_[q + "norm1.bias"].data, w_qkv=packed(ar.bflat), b_qkv=None,
+                    w_o=ar.b[q + "attn.project.weight"], b_o=P_[q + "attn.project.bias"].data,
+                    ln2_w=P_[q + "norm2.weight"].data, ln2_b=P_[q + "norm2.bias"].data,
+                    w_fc=ar.b[q + "mlp.fc1.weight"], b_fc=P_[q + "mlp.fc1.bias"].data,
+                    w_proj=ar.b[q + "mlp.fc2.weight"], b_proj=P_[q + "mlp.fc2.bias"].data, grads=grads))
+            hidden = mp.transformer.layers[0].mlp.fc1.weight.shape[0]
+            self._mstack = BlockStack(StackGeometry(D, mp.num_heads, mp.clip_length + mp.prefix_length, True, ops.ACT_RELU,
+                                                    False, head_dim=D // mp.num_heads, hidden=hidden), mblocks, Scratch(dev),
+                                      self.compute_dtype)
 
     # ---- mapper ----
+    def _tmapper_forward(self, prefix: torch.Tensor, train: bool):
+        """TransformerMapper.forward (train.py:235-240) on the generalised BlockStack (head_dim 96, ReLU, ratio 2)."""
+        ar, mp, st = self._arena, self.clip_project, self._mstack
+        B, dev = prefix.shape[0], prefix.device
+        CL, P, D = mp.clip_length, mp.prefix_length, mp.dim
+        T = CL + P
+        pb = torch.empty(B, mp.sizes[0], device=dev, dtype=self.compute_dtype)
+        ops.cast_f32_to_bf16(prefix.detach().float().contiguous(), pb)
+        lin = torch.empty(B, CL * D, device=dev, dtype=torch.float32)
+        ops.gemm_bf16(pb, ar.b["clip_project.linear.weight"], bias=ar.params["clip_project.linear.bias"].data, out_f32=lin)
+        saved = st.alloc_saved(B, dev, T=T) if train else None
+        x = saved["xs"][0, 0] if train else torch.empty(B * T, D, device=dev, dtype=torch.float32)
+        xv = x.view(B, T, D)
+        xv[:, :CL].copy_(lin.view(B, CL, D))                       # torch.cat((x, prefix), dim=1): data movement only
+        xv[:, CL:].copy_(ar.params["clip_project.prefix_const"].data)
+        xo = st.forward(x, B, saved=saved, T=T)
+        out = xo.view(B, T, D)[:, CL:].contiguous().view(B, P * D)  # [:, clip_length:] (train.py:239), dense for caption_embed
+        return out, (pb, saved) if train else None
+
+    def _tmapper_backward(self, msave, dx_gpt: torch.Tensor, dxb_gpt: torch.Tensor, B: int, S: int, acc, A):
+        """dx_gpt / dxb_gpt: fp32 / 16-bit gradient of the GPT-2 input rows [B*S, D]; the first P rows of every
+        sequence are the mapper's output."""
+        ar, mp, st = self._arena, self.clip_project, self._mstack
+        g = ar.g
+        pb, saved = msave
+        dev = dx_gpt.device
+        CL, P, D = mp.clip_length, mp.prefix_length, mp.dim
+        T = CL + P
+        dxm = torch.zeros(B * T, D, device=dev, dtype=torch.float32)
+        dxbm = torch.zeros(B * T, D, device=dev, dtype=self.compute_dtype)
+        dxm.view(B, T, D)[:, CL:].copy_(dx_gpt.view(B, S, D)[:, :P])
+        dxbm.view(B, T, D)[:, CL:].copy_(dxb_gpt.view(B, S, D)[:, :P])
+        for i, blk in enumerate(st.blocks):                          # packed q|kv grad view shares the q slot's state
+            if blk.grads is not None:
+                acc[id(blk.grads["w_qkv"])] = A(f"clip_project.transformer.layers.{i}.attn.to_queries.weight")
+        dxbm = st.backward(dxm, dxbm, saved, acc)
+        sc = st.scratch
+        pc, lw, lb = "clip_project.prefix_const", "clip_project.linear.weight", "clip_project.linear.bias"
+        ops.colsum(dxm.view(B, T * D)[:, CL * D:], g[pc].view(-1), sc.floats(ops.colsum_ws_floats(B, P * D)), R=B, C=P * D,
+                   ld=T * D, accumulate=A(pc))
+        dlin = dxbm.view(B, T * D)[:, :CL * D]
+        ops.gemm_bf16(dlin, pb, a_kcontig=False, b_kcontig=False, residual=g[lw] if A(lw) else None, out_f32=g[lw])
+        ops.colsum(dlin, g[lb], sc.floats(ops.colsum_ws_floats(B, CL * D)), R=B, C=CL * D, ld=T * D, accumulate=A(lb))
+
     def _mapper_forward(self, prefix: torch.Tensor, train: bool):
+        if self._mstack is not None:
+            return self._tmapper_forward(prefix, train)
         ar = self._arena
         B = prefix.shape[0]
         dev = prefix.device
@@ -275,7 +431,10 @@ class ClipCaptionModel(nn.Module):
         self._arena.refresh_shadows()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.clip_project.parameters()):
             raise NotImplementedError("differentiate through ClipCaptionModel.forward / caption_loss, not clip_project alone")
-        return self._mapper_forward(prefix, False)[0]
+        out = self._mapper_forward(prefix, False)[0]
+        if isinstance(self.clip_project, TransformerMapper):          # train.py:247 returns [B, prefix_length, D]
+            out = out.view(-1, self.prefix_length, self.model_embedding_size)
+        return out
 
     # ---- shared forward to the final hidden states ----
     def _hidden_forward(self, x: torch.Tensor, B: int, S: int, mask: Optional[torch.Tensor], saved: Optional[dict]):
@@ -400,7 +559,10 @@ class ClipCaptionModel(nn.Module):
             ops.colsum(dx, g[wpe][:S].view(-1), sc.floats(ops.colsum_ws_floats(B, S * D)), R=B, C=S * D, ld=S * D, accumulate=True)
             ops.embed_scatter_add(c["ids"].view(-1), dx, g[wte_name], rows=B * Lt, L=Lt, seq_stride=S, seq_off=P)
         # mapper: d prefix_proj = dx[b, :P]  -> a [B, P*D] matrix with row stride S*D inside dx / dxb
-        if p["clip_project.model.2.weight"].requires_grad:
+        if self._mstack is not None:
+            if p["clip_project.linear.weight"].requires_grad:
+                self._tmapper_backward(c["msave"], dx, dxb, B, S, acc, A)
+        elif p["clip_project.model.2.weight"].requires_grad:
             pb, h1 = c["msave"]
             n_in, n_hid, n_out = self.clip_project.sizes
             dproj = dxb.view(B, S * D)[:, :P * D]

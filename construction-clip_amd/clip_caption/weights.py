@@ -87,3 +87,35 @@ def synthetic_caption_batch(b: int, geo: CaptionGeometry, caption_len: int = 40,
     prefix = torch.randn(b, geo.prefix_size, generator=g)
     mask = torch.ones(b, geo.prefix_length + geo.attribute_length + caption_len)
     return tokens, mask, prefix, attribute
+
+
+def init_transformer_mapper_state_dict(geo: CaptionGeometry, clip_length: int, num_layers: int = 8, seed: int = 567,
+                                       mlp_ratio: float = 2.0) -> Dict[str, torch.Tensor]:
+    """`clip_project.*` tensors of the reference's TransformerMapper (CLIP_prefix_caption/train.py:233-248), nn.Linear /
+    nn.LayerNorm default inits with perturbed LayerNorm affines (so every term is exercised)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def un(*shape, bound=1.0):
+        return (torch.rand(*shape, generator=g) * 2 - 1) * bound
+
+    D, h = geo.n_embd, int(geo.n_embd * mlp_ratio)
+    sd: Dict[str, torch.Tensor] = {}
+    p = "clip_project."
+    sd[p + "prefix_const"] = torch.randn(geo.prefix_length, D, generator=g)
+    for i in range(num_layers):
+        q = f"{p}transformer.layers.{i}."
+        sd[q + "norm1.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+        sd[q + "norm1.bias"] = 0.1 * torch.randn(D, generator=g)
+        sd[q + "attn.to_queries.weight"] = un(D, D, bound=D ** -0.5)
+        sd[q + "attn.to_keys_values.weight"] = un(2 * D, D, bound=D ** -0.5)
+        sd[q + "attn.project.weight"] = un(D, D, bound=D ** -0.5)
+        sd[q + "attn.project.bias"] = un(D, bound=D ** -0.5)
+        sd[q + "norm2.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+        sd[q + "norm2.bias"] = 0.1 * torch.randn(D, generator=g)
+        sd[q + "mlp.fc1.weight"] = un(h, D, bound=D ** -0.5)
+        sd[q + "mlp.fc1.bias"] = un(h, bound=D ** -0.5)
+        sd[q + "mlp.fc2.weight"] = un(D, h, bound=h ** -0.5)
+        sd[q + "mlp.fc2.bias"] = un(D, bound=h ** -0.5)
+    sd[p + "linear.weight"] = un(clip_length * D, geo.prefix_size, bound=geo.prefix_size ** -0.5)
+    sd[p + "linear.bias"] = un(clip_length * D, bound=geo.prefix_size ** -0.5)
+    return sd

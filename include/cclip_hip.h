@@ -120,6 +120,11 @@ typedef struct cclip_attn_desc {
 } cclip_attn_desc;
 int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream);
+/* Generic small attention for the reference's TransformerMapper (CLIP_prefix_caption/train.py:141-171: 8 heads of
+ * 96 over 40 tokens): any head_dim <= 128 (multiple of 8), T <= 64, no mask; same descriptor; LDS must hold one
+ * (batch, head): 4*T*(head_dim+2) + 2*T*(T+1) + T floats <= 160 KiB in backward. */
+int cclip_attention_small_fwd(const cclip_attn_desc* d, hipStream_t stream);
+int cclip_attention_small_bwd(const cclip_attn_desc* d, hipStream_t stream);
 
 /* ---- exact fp32 GEMM (f32-input MFMA), generic strides ---------------------------------------
  * C[m*ldc+n] = alpha' * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m*ldc+n], with
@@ -209,6 +214,8 @@ int cclip_layernorm_bwd_f16(const void* dy, int32_t dy_is_f16, int64_t lddy, con
                             float* ws, hipStream_t stream);
 int cclip_attention_fwd_f16(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_bwd_f16(const cclip_attn_desc* d, hipStream_t stream);
+int cclip_attention_small_fwd_f16(const cclip_attn_desc* d, hipStream_t stream);
+int cclip_attention_small_bwd_f16(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_patchify_f16(const float* image, void* out_f16, int32_t B, int32_t R, int32_t P, hipStream_t stream);
 int cclip_colsum_f16(const void* in, int32_t in_is_f16, int64_t ld, int32_t R, int32_t C, float* out,
                      int32_t accumulate, float* ws, hipStream_t stream);

@@ -109,11 +109,15 @@ def gpt2_forward(sd: SD, inputs_embeds: Tensor, attention_mask: Optional[Tensor]
 
 
 def caption_forward(sd: SD, tokens: Tensor, prefix: Tensor, attribute: Tensor, mask: Optional[Tensor],
-                    prefix_length: int, n_head: int = 12) -> Tensor:
-    """ClipCaptionModel.forward (train.py:256-269) with the default MLP mapper: returns logits [B, P+A+L, V]."""
+                    prefix_length: int, n_head: int = 12, clip_length: Optional[int] = None) -> Tensor:
+    """ClipCaptionModel.forward (train.py:256-269): returns logits [B, P+A+L, V].  The mapper is the MLP unless the
+    state_dict holds a TransformerMapper (then clip_length must be given)."""
     wte = sd["model.transformer.wte.weight"].float()
     emb_text = wte[torch.cat((attribute, tokens), dim=1).long()]
-    pre = mlp_mapper(sd, prefix).view(-1, prefix_length, wte.shape[1])
+    if "clip_project.prefix_const" in sd:
+        pre = transformer_mapper(sd, prefix, clip_length)
+    else:
+        pre = mlp_mapper(sd, prefix).view(-1, prefix_length, wte.shape[1])
     return gpt2_forward(sd, torch.cat((pre, emb_text), dim=1), mask, n_head)
 
 

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "construction-clip_amd")]
 
 from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text  # noqa: E402
-from clip_caption.weights import GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch  # noqa: E402
+from clip_caption.weights import (GPT2_MODELS, init_caption_state_dict, init_transformer_mapper_state_dict,  # noqa: E402
+                                  synthetic_caption_batch)
 from oracle import caption_oracle as CO  # noqa: E402
 from oracle import clip_oracle as O  # noqa: E402
 
@@ -89,12 +90,32 @@ def caption_case(name: str, b: int, lc: int, seed: int):
                 grad_norms={k: v.grad.norm() for k, v in sdg.items() if v.grad is not None})
 
 
+def caption_tmapper_case(name: str, b: int, lc: int, seed: int, clip_length: int, num_layers: int):
+    """ClipCaptionModel with --mapping_type transformer (train.py:397): 8 heads, ReLU, mlp_ratio 2."""
+    geo = GPT2_MODELS[name]
+    sd = {k: v for k, v in init_caption_state_dict(geo, seed).items() if not k.startswith("clip_project.")}
+    sd.update(init_transformer_mapper_state_dict(geo, clip_length, num_layers, seed + 7))
+    tokens, mask, prefix, attribute = synthetic_caption_batch(b, geo, lc, seed + 1)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "model.lm_head.weight"}
+    sdg["model.lm_head.weight"] = sdg["model.transformer.wte.weight"]
+    logits = CO.caption_forward(sdg, tokens, prefix, attribute, mask, geo.prefix_length, geo.n_head, clip_length=clip_length)
+    loss = CO.caption_loss(logits, tokens, geo.prefix_length, geo.attribute_length)
+    loss.backward()
+    with torch.no_grad():
+        mapped = CO.transformer_mapper(sd, prefix, clip_length)
+    keys = [k for k in sdg if k.startswith("clip_project.") and (".layers.0." in k or ".layers.1.attn" in k or "linear" in k or "prefix_const" in k)]
+    return dict(model=name, seed=seed, b=b, lc=lc, clip_length=clip_length, num_layers=num_layers, mapper_out=sample(mapped, 8192),
+                loss=loss.detach(), grads={k: sample(sdg[k].grad) for k in keys},
+                grad_norms={k: v.grad.norm() for k, v in sdg.items() if v.grad is not None and k.startswith("clip_project.")})
+
+
 def main():
     torch.manual_seed(0)
     torch.save(clip_case("test-tiny", 9, 11, True), os.path.join(OUT, "clip_test_tiny.pt"))
     torch.save(clip_case("test-small", 9, 12, True), os.path.join(OUT, "clip_test_small.pt"))
     torch.save(clip_case("ViT-B/32", 9, 567, False), os.path.join(OUT, "clip_vit_b32.pt"))
     torch.save(caption_case("test-tiny", 3, 12, 21), os.path.join(OUT, "caption_test_tiny.pt"))
+    torch.save(caption_tmapper_case("test-tiny", 3, 12, 23, clip_length=6, num_layers=2), os.path.join(OUT, "caption_tmapper_tiny.pt"))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

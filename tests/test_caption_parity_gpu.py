@@ -115,3 +115,66 @@ def test_key_padding_mask_is_honoured():
         b = model(tokens, prefix, attribute, m2).logits
     assert not torch.equal(a[:, -1], b[:, -1])            # last position no longer sees the masked keys... nor itself
     assert torch.equal(a[:, : a.shape[1] - 3], b[:, : a.shape[1] - 3])   # causal: earlier positions never saw them
+
+
+# ---- --mapping_type transformer (train.py:233-248, 397) ----------------------------------------------------------------
+def _setup_tmapper():
+    from clip_caption import (ClipCaptionModel, GPT2_MODELS, MappingType, init_caption_state_dict, init_transformer_mapper_state_dict,
+                              synthetic_caption_batch)
+    g = torch.load(os.path.join(GOLD, "caption_tmapper_tiny.pt"), weights_only=True)
+    geo = GPT2_MODELS[g["model"]]
+    model = ClipCaptionModel(geo.prefix_length, clip_length=g["clip_length"], prefix_size=geo.prefix_size, num_layers=g["num_layers"],
+                             mapping_type=MappingType.Transformer, gpt2_type=geo)
+    sd = {k: v for k, v in init_caption_state_dict(geo, g["seed"]).items() if not k.startswith("clip_project.")}
+    sd.update(init_transformer_mapper_state_dict(geo, g["clip_length"], g["num_layers"], g["seed"] + 7))
+    assert set(sd) == set(model.state_dict())                 # the reference's checkpoint key layout, exactly
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    tokens, mask, prefix, attribute = [t.cuda() for t in synthetic_caption_batch(g["b"], geo, g["lc"], g["seed"] + 1)]
+    return g, geo, model, tokens, mask, prefix, attribute
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_transformer_mapper_forward_loss_grads(half):
+    g, geo, model, tokens, mask, prefix, attribute = _setup_tmapper()
+    if half:
+        model.half()
+    ftol, ltol, gtol = (3e-3, 6e-4, 2e-2) if half else (1.5e-2, 5e-3, 6e-2)
+    with torch.no_grad():
+        mapped = model.clip_project(prefix)
+    assert mapped.shape == (g["b"], geo.prefix_length, geo.n_embd)
+    assert rel(sample(mapped, 8192), g["mapper_out"]) < ftol
+    loss = model.caption_loss(tokens, prefix, attribute, mask)
+    loss.backward()
+    assert abs(loss.item() - g["loss"].item()) < ltol
+    params = dict(model.named_parameters())
+    for k, ref in g["grads"].items():
+        assert params[k].grad is not None, k
+        assert rel(sample(params[k].grad), ref) < gtol, (k, rel(sample(params[k].grad), ref))
+    for k, nrm in g["grad_norms"].items():
+        assert abs(params[k].grad.norm().item() - nrm.item()) <= 0.04 * nrm.item() + 1e-7, k
+
+
+def test_transformer_mapper_reference_shape_runs():
+    """The reference's own configuration (train.py:391-399: prefix_length 20, clip_length 20 -> 40 tokens, 8 heads x 96, 8 layers) -
+    a finite loss, gradients on every mapper tensor, and loss decreases under the fused AdamW."""
+    from clip import optim as coptim
+    from clip_caption import ClipCaptionPrefix, CaptionGeometry, MappingType, init_caption_state_dict, synthetic_caption_batch
+    geo = CaptionGeometry(vocab_size=1000, n_layer=2)
+    torch.manual_seed(5)
+    model = ClipCaptionPrefix(20, clip_length=20, prefix_size=512, num_layers=8, mapping_type=MappingType.Transformer, gpt2_type=geo)
+    model.model.load_state_dict({k[len("model."):]: v for k, v in init_caption_state_dict(geo, 5).items() if k.startswith("model.")})
+    model = model.cuda().train()                 # the mapper keeps its constructor (nn.Linear-style) initialisation
+    tokens, mask, prefix, attribute = [t.cuda() for t in synthetic_caption_batch(4, geo, 16, 9)]
+    opt = coptim.AdamW(model, lr=1e-3)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = model.caption_loss(tokens, prefix, attribute, mask)
+        loss.backward()
+        losses.append(loss.item())
+        bad = [n for n, p in model.clip_project.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+        assert not bad, bad
+        assert all(p.grad.abs().max() > 0 for p in model.clip_project.parameters())
+        opt.step()
+    assert losses[-1] < losses[0], losses

@@ -130,6 +130,46 @@ def test_attention_fwd_bwd(B, T, H, causal, pad):
     close("attn dv", dqkv[:, 2 * D:], gref[:, 2 * D:], 3e-2)
 
 
+@pytest.mark.parametrize("B,T,H,dh,dt", [(3, 40, 8, 96, torch.bfloat16), (2, 10, 8, 16, torch.bfloat16), (2, 48, 2, 128, torch.float16), (2, 64, 4, 64, torch.bfloat16),
+                                         (1, 1, 1, 8, torch.bfloat16), (2, 33, 3, 40, torch.float16)])
+def test_attention_small_fwd_bwd(B, T, H, dh, dt):
+    """Generic-head_dim attention (TransformerMapper: 8 heads x 96, 40 tokens) against fp32 torch on the same 16-bit inputs."""
+    o = ops()
+    g = G(B * 1000 + T + dh)
+    D = H * dh
+    qkv = torch.randn(B * T, 3 * D, device="cuda", generator=g).to(dt)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    out = torch.full((B * T, D), float("nan"), device="cuda", dtype=dt)
+    lse = torch.empty(B, H, T, device="cuda")
+    o.attention_small_fwd(q, k, v, out, B=B, T=T, H=H, head_dim=dh, lse=lse)
+    f = qkv.float().view(B, T, 3, H, dh).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    sc = (f[0] @ f[1].transpose(-1, -2)) * dh ** -0.5
+    ref = torch.softmax(sc, dim=-1) @ f[2]
+    tol = 1.5e-2 if dt == torch.bfloat16 else 2e-3
+    close("attn_small fwd", out, ref.permute(0, 2, 1, 3).reshape(B * T, D), tol)
+    close("attn_small lse", lse, torch.logsumexp(sc, dim=-1), 1e-4, 1e-4)
+    dout = torch.randn(B * T, D, device="cuda", generator=g).to(dt)
+    dqkv = torch.full((B * T, 3 * D), float("nan"), device="cuda", dtype=dt)
+    o.attention_small_bwd(q, k, v, out, lse, dout, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B=B, T=T, H=H, head_dim=dh)
+    ref.backward(dout.float().view(B, T, H, dh).permute(0, 2, 1, 3))
+    gref = f.grad.permute(1, 3, 0, 2, 4).reshape(B * T, 3 * D)
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        close("attn_small " + nm, dqkv[:, i * D:(i + 1) * D], gref[:, i * D:(i + 1) * D], 2 * tol)
+
+
+def test_attention_small_rejects_unsupported_shapes():
+    from cclip_hip._lib import CclipError
+    o = ops()
+    x = torch.zeros(65 * 2, 3 * 64, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(65 * 2, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(CclipError):
+        o.attention_small_fwd(x[:, :64], x[:, 64:128], x[:, 128:], out, B=2, T=65, H=1, head_dim=64)     # T > 64
+    x = torch.zeros(8, 3 * 12, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(CclipError):
+        o.attention_small_fwd(x[:, :12], x[:, 12:24], x[:, 24:], out, B=1, T=8, H=1, head_dim=12)          # head_dim % 8
+
+
 @pytest.mark.parametrize("M,N,K,ta,tb", [(9, 9, 512, False, False), (1024, 1024, 512, False, False), (100, 70, 33, True, False),
                                          (65, 130, 768, False, True), (512, 768, 100, True, True)])
 def test_gemm_f32(M, N, K, ta, tb):
