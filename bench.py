@@ -1,12 +1,15 @@
 """Headline benchmark: image-text pairs/sec of the CLIP ViT-B/32 contrastive step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--mode train|fwd] [--batch 1024]
+    python bench.py --gpus N --steps K --warmup W [--mode train|fwd|image|caption] [--batch 1024]
 
 Workload (BASELINE.json configs[1]): CLIP/train.py's step `model(image, text)` -> symmetric CE ->
 backward -> AdamW, scaled to bs = 1024 pairs per GPU, synthetic 224x224 N(0,1) images + 77-token captions
 (SURVEY.md 8d), seeded OpenAI-style weights, bf16 MFMA operands / fp32 accumulate / fp32 masters.
 One "step" = encode_image + encode_text + logits + loss + full backward + optimiser step over one batch.
-`--mode fwd` times encode + logits only (reported as an extra, never as `value` by default).
+`--mode fwd` times encode + logits only, `--mode image` encode_image alone (the "40 % of the bf16 roofline"
+target of BASELINE.md is quoted on it), `--mode caption` BASELINE.json configs[3] (ClipCaptionModel: MLP mapper +
+GPT-2-small, V = 21128, bs = 256, 40 caption tokens -> S = 80, fwd + bwd + AdamW on pre-extracted CLIP prefixes).
+Those are extras with their own metric names; the default line is always the train step.
 N > 1: one process per GPU (torchrun contract), weak scaling (per-GPU batch fixed), embedding
 all-gather + reduce-scatter and SUM all-reduce of the flat gradient arena over RCCL.
 
@@ -31,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "construction-clip_amd")]
 
 PAIR_FWD_FLOPS = 14_777_163_776          # encode_image 8 817 623 040 + encode_text 5 959 540 736
+IMAGE_FWD_FLOPS = 8_817_623_040
+CAPTION_FWD_FLOPS = 16_420_000_000 + 243_793_920   # GPT-2 prefix forward at S=80, V=21128 + mapper
 PEAK_BF16 = 2.5e15                       # dense bf16 MFMA, MI355X_MICROARCH.md
 
 
@@ -84,6 +89,123 @@ def cpu_baseline(mode: str, budget_s: float = 12.0):
                        f"median of {len(times) - 1 or 1} iterations after 1 warm-up, torch CPU {cores} threads")
 
 
+def gemm_roofline(ev, nprof, traffic=None, traffic_src=None):
+    """Fold the (start, end, flops, layout, shape) HIP-event records of ops.GEMM_EVENTS into the `roofline` object."""
+    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)
+    tot_fl = sum(f for _, _, f, *_ in ev)
+    by = {}
+    for e0, e1, f, lay, _shape in ev:
+        k = {(1, 1): "fwd", (1, 0): "dgrad", (0, 0): "wgrad"}[lay]
+        t, fl, n = by.get(k, (0.0, 0.0, 0))
+        by[k] = (t + e0.elapsed_time(e1), fl + f, n + 1)
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="gemm_bf16_kernel<*> (all layouts and tile configs)", achieved=round(ach, 1),
+                peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(ach * 1e12 / PEAK_BF16, 4), traffic=traffic,
+                traffic_unit="HBM-side bytes per launch (PMC, includes Infinity-Cache hits)", traffic_source=traffic_src,
+                flops_per_launch=round(tot_fl / max(len(ev), 1)),
+                launches_per_step=len(ev) // nprof, gemm_ms_per_step=round(tot_ms / nprof, 3),
+                by_layout={k: dict(tflops=round(fl / (t * 1e-3) / 1e12, 1), ms_per_step=round(t / nprof, 3), launches=n // nprof)
+                           for k, (t, fl, n) in by.items()})
+
+
+def caption_main(args, rank, world, dev, B, cdt):
+    """BASELINE.json configs[3]: CLIP_prefix_caption/train.py step (train.py:347-361) on pre-extracted prefixes."""
+    import torch.distributed as dist
+    from clip import optim as coptim
+    from clip import parallel
+    from clip_caption import ClipCaptionModel, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch
+    from cclip_hip import ops
+    geo = GPT2_MODELS["ckiplab/gpt2-base-chinese"]
+    Lc = 40
+    model = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+    model.load_state_dict(init_caption_state_dict(geo, 567))
+    model = model.to(dev).train()
+    if cdt == torch.float16:
+        model.half()
+    parallel.broadcast_parameters(model)
+    opt = coptim.AdamW(model, lr=2e-5)                                     # train.py:336 (lr 2e-5)
+    sched = coptim.get_linear_schedule_with_warmup(opt, 5000, 10 * 1000)   # train.py:338-340
+    tokens, mask, prefix, attribute = [t.to(dev) for t in synthetic_caption_batch(B, geo, Lc, 567 + rank)]
+
+    def step():
+        opt.zero_grad()
+        loss = model.caption_loss(tokens, prefix, attribute, mask)
+        loss.backward()
+        parallel.allreduce_gradients(model, None)
+        opt.step(grad_scale=1.0 / world)        # every rank's loss is its local mean: average the summed gradients
+        sched.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"caption warmup step {i} done")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    nprof = min(2, args.steps)
+    if rank == 0:
+        ops.GEMM_EVENTS = []
+    os.environ["CCLIP_WGRAD_STREAM"] = "0"
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        ev, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+        S = geo.prefix_length + geo.attribute_length + Lc
+        out = {"metric": "caption samples/sec (ClipCaptionModel train step: MLP mapper + GPT-2-small, bs=256)",
+               "value": round(B * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"CLIP_prefix_caption/train.py step (fwd+bwd+AdamW), MLP mapper 512->7680->15360 + GPT-2-small "
+                          f"V={geo.vocab_size}, bs={B}/GPU, prefix 20 + attribute 20 + {Lc} caption tokens (S={S}), seeded synthetic weights",
+                          "global_batch": B * world, "parallelism": f"dp{world}", "mode": "caption"},
+               "step_mfu_bf16": round(3 * CAPTION_FWD_FLOPS * B * world / (dt / args.steps) / (PEAK_BF16 * world), 4),
+               "loss": round(float(loss.item()), 5), "roofline": gemm_roofline(ev, nprof), "cpu_baseline": None}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = caption_cpu_baseline(geo, Lc)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def caption_cpu_baseline(geo, Lc, budget_s: float = 12.0):
+    from clip_caption import init_caption_state_dict, synthetic_caption_batch
+    from oracle import caption_oracle as CO
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    bs = 8
+    sd = init_caption_state_dict(geo, 567)
+    tokens, mask, prefix, attribute = synthetic_caption_batch(bs, geo, Lc, 568)
+    times, t_all = [], time.time()
+    for it in range(12):
+        t0 = time.time()
+        sdg = {k: v.detach().requires_grad_(True) for k, v in sd.items() if k != "model.lm_head.weight"}
+        sdg["model.lm_head.weight"] = sdg["model.transformer.wte.weight"]
+        lg = CO.caption_forward(sdg, tokens, prefix, attribute, mask, geo.prefix_length, geo.n_head)
+        CO.caption_loss(lg, tokens, geo.prefix_length, geo.attribute_length).backward()
+        times.append(time.time() - t0)
+        log(f"caption cpu baseline iteration {it}: {times[-1]:.2f}s")
+        if time.time() - t_all > budget_s and it >= 2:
+            break
+    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return dict(value=bs / t, unit="samples/s", cores=cores, kind="port",
+                sample=f"oracle/caption_oracle.py fp32 fwd+bwd, batch {bs}, median of {len(times) - 1 or 1} iterations after 1 warm-up, "
+                       f"torch CPU {cores} threads")
+
+
 def log(msg: str):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -98,8 +220,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
-    ap.add_argument("--mode", choices=["train", "fwd"], default="train")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default 1024; 256 for --mode caption)")
+    ap.add_argument("--mode", choices=["train", "fwd", "image", "caption"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="ViT-B/32")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit MFMA operand type")
@@ -121,7 +243,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     geo = MODELS[args.model]
-    B = args.batch
+    B = args.batch or (256 if args.mode == "caption" else 1024)
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if args.mode == "caption":
+        return caption_main(args, rank, world, dev, B, cdt)
 
     model = clip.build_model(init_state_dict(geo, 567), torch.bfloat16 if args.dtype == "bf16" else torch.float16).to(dev)
     model.train()
@@ -139,6 +264,9 @@ def main():
         return model.encode_image_text(image, text)
 
     def step():
+        if args.mode == "image":
+            with torch.no_grad():
+                return [model.encode_image(image).float().sum()]
         if args.mode == "fwd":
             with torch.no_grad():
                 fi, ft = encode_both()
@@ -191,14 +319,6 @@ def main():
     if rank == 0:
         ev = ops.GEMM_EVENTS
         ops.GEMM_EVENTS = None
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in ev)
-        tot_fl = sum(f for _, _, f, *_ in ev)
-        by = {}
-        for e0, e1, f, lay, _shape in ev:
-            k = {(1, 1): "fwd", (1, 0): "dgrad", (0, 0): "wgrad"}[lay]
-            t, fl, n = by.get(k, (0.0, 0.0, 0))
-            by[k] = (t + e0.elapsed_time(e1), fl + f, n + 1)
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "r01_train_bs1024_hbm_traffic_pmc.json")
         if os.path.exists(tp) and args.mode == "train" and B == 1024 and args.dtype == "bf16":
@@ -207,26 +327,22 @@ def main():
             gf = json.load(open(tp))["gemm_family"]
             traffic = round((gf["fetch_mb_per_launch_corrected"] + gf["write_mb_per_launch"]) * 1e6)
             traffic_src = "profiles/r01_train_bs1024_hbm_traffic_pmc.json"
-        roof = dict(bound="mfma", kernel="gemm_bf16_kernel<*> (all layouts and tile configs)", achieved=round(ach, 1),
-                    peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(ach * 1e12 / PEAK_BF16, 4), traffic=traffic,
-                    traffic_unit="HBM-side bytes per launch (PMC, includes Infinity-Cache hits)", traffic_source=traffic_src,
-                    flops_per_launch=round(tot_fl / max(len(ev), 1)),
-                    launches_per_step=len(ev) // nprof, gemm_ms_per_step=round(tot_ms / nprof, 3),
-                    by_layout={k: dict(tflops=round(fl / (t * 1e-3) / 1e12, 1), ms_per_step=round(t / nprof, 3), launches=n // nprof)
-                               for k, (t, fl, n) in by.items()})
+        roof = gemm_roofline(ev, nprof, traffic, traffic_src)
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         pairs = B * world * args.steps
         value = pairs / dt
-        step_flops = PAIR_FWD_FLOPS * (3 if args.mode == "train" else 1) * B
+        step_flops = (IMAGE_FWD_FLOPS if args.mode == "image" else PAIR_FWD_FLOPS * (3 if args.mode == "train" else 1)) * B
         out = {
-            "metric": "image-text pairs/sec (encode+logits) ViT-B/32 bs=1024 at 1/2/4/8 MI355X",
-            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": ("images/sec encode_image ViT-B/32 bs=1024" if args.mode == "image"
+                       else "image-text pairs/sec (encode+logits) ViT-B/32 bs=1024 at 1/2/4/8 MI355X"),
+            "value": round(value, 1), "unit": "images/s" if args.mode == "image" else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("CLIP/train.py contrastive fine-tune step (fwd+bwd+AdamW)" if args.mode == "train"
+                                    else "encode_image forward only" if args.mode == "image"
                                     else "encode_image+encode_text+logits forward only") + f", {args.model}, bs={B}/GPU, "
                        "224x224 N(0,1) images + 77-token captions, seeded synthetic weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "mode": args.mode},
@@ -236,7 +352,7 @@ def main():
         }
         log("roofline leg done")
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.mode)
+            out["cpu_baseline"] = cpu_baseline("fwd" if args.mode == "image" else args.mode)
             log("cpu baseline done")
         else:
             out["cpu_baseline"] = None

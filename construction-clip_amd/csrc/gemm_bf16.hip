@@ -63,6 +63,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }  // namespace CCLIP_NS
 using namespace CCLIP_NS;
 
+#ifdef CCLIP_GEMM_STAMPS
+static unsigned long long* g_stamps = nullptr;
+extern "C" void CCLIP_FN(cclip_gemm_debug_set_stamps)(void* buf) { g_stamps = (unsigned long long*)buf; }
+#endif
+
 extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return CCLIP_ERR_ARG;
   if ((d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
@@ -87,6 +92,9 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   a.aux = (const bf16*)d->aux; a.ldaux = d->ldaux;
   a.out_f32 = d->out_f32; a.out_bf16 = (bf16*)d->out_bf16; a.out_pre = (bf16*)d->out_pre_bf16; a.ldc = d->ldc;
   a.act = d->act; a.split_ws = splits > 1 ? d->split_ws : nullptr;
+#ifdef CCLIP_GEMM_STAMPS
+  a.stamps = g_stamps;
+#endif
 
   int cfg = d->tile_config;
   if (cfg <= 0 || cfg > 3) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);

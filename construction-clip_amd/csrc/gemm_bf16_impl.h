@@ -1,6 +1,7 @@
 // Implementation template of the bf16 MFMA GEMM (see gemm_bf16.hip for the description); included by the
 // per-configuration translation units gemm_bf16_cfg*.hip so that they compile in parallel.
 #pragma once
+#include <type_traits>
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
@@ -23,7 +24,19 @@ struct GemmArgs {
   float* out_f32; bf16* out_bf16; bf16* out_pre; long ldc;
   int act;
   float* split_ws;   // != nullptr: raw fp32 partial tile stores to split_ws[z][M][N]
+#ifdef CCLIP_GEMM_STAMPS
+  unsigned long long* stamps;   // diagnostics build only: [tile][8] = hw id, t_start, t_issued, t_first, t_kdone, t_end (100 MHz)
+#endif
 };
+
+#ifdef CCLIP_GEMM_STAMPS
+#define STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = wall_clock64(); } while (0)
+// fine stamps (core clock) of K iteration kt0+5, lane 0 of every wave: region after the per-tile records, [tile][wave 0..7][8]
+#define ISTAMP(i) do { if (p.stamps && kt == kt0 + 5 && lane == 0) p.stamps[(size_t)gridDim.x * gridDim.y * 8 + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#define ISTAMP(i) do {} while (0)
+#endif
 
 // n-permutation: position i (0..15) of MFMA n-tile nt (0..3) of a wave's 64-column block maps to
 // local column P = 8*(i>>2) + 32*(nt>>1) + 4*(nt&1) + (i&3).  With the accumulator map
@@ -113,6 +126,72 @@ __device__ __forceinline__ float act_apply(float v, float a) {
   }
 }
 
+__device__ __forceinline__ void epi_bias(const GemmArgs& p, int col_base, int g, float (&bsv)[2][8]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int n0 = col_base + 32 * h + 8 * g;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bsv[h][r] = 0.f;
+    if (p.bias && !p.split_ws && n0 < p.N) {
+      if (n0 + 8 <= p.N) {
+        const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
+        bsv[h][0] = b0.x; bsv[h][1] = b0.y; bsv[h][2] = b0.z; bsv[h][3] = b0.w;
+        bsv[h][4] = b1.x; bsv[h][5] = b1.y; bsv[h][6] = b1.z; bsv[h][7] = b1.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) if (n0 + r < p.N) bsv[h][r] = p.bias[n0 + r];
+      }
+    }
+  }
+}
+
+// Epilogue operand loads (fp32 residual rows, 16-bit aux rows) of the EB m-tiles starting at m-tile mb.  A lane owns,
+// per (m-tile, half h), the 8-column run n0..n0+7 of one row; ragged right edges are read per element.
+template <int EB, bool HAS_AUX, bool DO_RES, bool DO_AUX>
+__device__ __forceinline__ void epi_loads(const GemmArgs& p, int row_base, int col_base, int mb, int li, int g,
+                                          float (&rres)[EB][2][8], bf16x8 (&raux)[HAS_AUX ? EB : 1][2]) {
+#pragma unroll
+  for (int mi = 0; mi < EB; ++mi) {
+    const int m = row_base + 16 * (mb + mi) + li;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n0 = col_base + 32 * h + 8 * g;
+      const bool live = m < p.M && n0 < p.N && !p.split_ws;
+      const bool full = n0 + 8 <= p.N;
+      if (DO_RES) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rres[mi][h][r] = 0.f;
+      }
+      if (DO_RES && live && p.residual) {
+        const float* rp = p.residual + (long)m * p.ldr + n0;
+        if (full) {
+          const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+          rres[mi][h][0] = r0.x; rres[mi][h][1] = r0.y; rres[mi][h][2] = r0.z; rres[mi][h][3] = r0.w;
+          rres[mi][h][4] = r1.x; rres[mi][h][5] = r1.y; rres[mi][h][6] = r1.z; rres[mi][h][7] = r1.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) if (n0 + r < p.N) rres[mi][h][r] = rp[r];
+        }
+      }
+      if (HAS_AUX && DO_AUX) {
+        bf16x8 ax;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ax[r] = (bf16)0.f;
+        if (live) {
+          const bf16* ap = p.aux + (long)m * p.ldaux + n0;
+          if (full) {
+            ax = *(const bf16x8*)ap;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) ax[r] = ap[r];
+          }
+        }
+        raux[HAS_AUX ? mi : 0][h] = ax;
+      }
+    }
+  }
+}
+
 // WM x WN waves, each a (16*MT)x64 output sub-tile: block tile = (16*MT*WM) x (64*WN).  STAGES LDS stages; the DMA
 // for tile kt+STAGES-1 is issued while tile kt is multiplied, with a COUNTED s_waitcnt vmcnt so that the
 // younger stages stay in flight across the barrier (a plain __syncthreads would drain them).
@@ -137,11 +216,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   const int a_off = (wm0 >> 7) * TILE_BYTES, a_row = wm0 & 127;   // sub-tile + row/col offset inside it
   const int b_off = (wn >> 1) * TILE_BYTES, b_row = (wn & 1) * 64;
 
+#ifdef CCLIP_GEMM_STAMPS
+  if (p.stamps && threadIdx.x == 0) {
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
+  STAMP(1);
   f32x4 acc[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // 64x64-per-wave configurations have the registers to fetch the epilogue's residual / aux rows NOW, ahead of the
+  // operand DMA: the loads are the oldest entries of the in-order vmcnt queue (every counted wait below stays
+  // valid), they land under the K loop's MFMA phase, and the epilogue is left with math and fire-and-forget
+  // stores - one full memory round trip per tile and half of the epilogue's HBM traffic leave the serial path.
+  constexpr bool HAS_AUX = ACT >= CCLIP_ACT_DQUICKGELU;
+  constexpr bool PRE = MT <= 4;
+  constexpr int EB = PRE ? MT : 2;                               // m-tiles per epilogue batch (register budget)
+  const int li = lane & 15, g = lane >> 4;
+  float rres[EB][2][8];
+  bf16x8 raux[HAS_AUX ? EB : 1][2];
+  float bsv[2][8];
+  if (PRE) {
+    epi_bias(p, bn0 + wn0, g, bsv);
+    // (the activation-derivative kernels are at the 256-VGPR limit: they prefetch their aux rows only)
+    epi_loads<EB, HAS_AUX, !HAS_AUX, HAS_AUX>(p, bm0 + wm0, bn0 + wn0, 0, li, g, rres, raux);
+  }
 
 #pragma unroll
   for (int s = 0; s < PD; ++s) {
@@ -151,19 +255,45 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt0 + s) * BK, sb + NSA * TILE_BYTES, wave, lane);
     }
   }
+  STAMP(2);
   int cur = 0;                                                   // stage holding tile kt
-  for (int kt = kt0; kt < kt1; ++kt) {
+  // One K-tile iteration.  DMA = true (steady state, kt + PD < kt1): the operand DMA of tile kt+PD is part of the same
+  // basic block as the MFMAs and is dealt out BETWEEN them (one global_load_lds per few MFMAs): issuing the 6-8 DMA
+  // instructions back to back cost ~500 clocks per wave per iteration with the matrix pipe idle (in-kernel stamps,
+  // tools/gemm_stamps.py), almost as much as the iteration's MFMAs themselves.  DMA = false: the last PD iterations.
+  auto k_iter = [&](int kt, auto dma_tag, int wait_tiles) {
+    constexpr bool DMA = decltype(dma_tag)::value;
+    // In-process A/B against the previous build (tools/gemm_ab.py, MI355X): dealing the DMA out between k-step 1's
+    // MFMAs (ILV) is worth -14..-34 % on the K-strided layouts of the 8-wave configurations (dgrad / wgrad: twice the
+    // LDS read instructions) and -2..-7 % with 3 stages, but +5..10 % on 2-stage forward-layout kernels, whose DMA
+    // then starts too late to land within one iteration: the 256x256 configuration deals it out between k-step 0's
+    // FIRST MFMAs instead (ILV_EARLY, neutral), and the 128x128 one keeps the DMA ahead of the fragment reads.
+    constexpr bool ILV = STAGES >= 3 || (MT >= 8 && !(A_KC && B_KC)) || (!A_KC && !B_KC);
+    constexpr bool ILV_EARLY = !ILV && MT >= 8;
     // tile kt has landed for this wave once at most the younger stages' DMAs are outstanding; the barrier then
     // (a) publishes every wave's part of tile kt and (b) proves every wave is done reading stage cur-1
-    const int ahead = kt1 - 1 - kt;                              // tiles already issued beyond kt: min(ahead, PD-1)
-    if (PD >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
-    else if (PD >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
+    ISTAMP(0);
+#ifdef CCLIP_GEMM_STAMPS
+    if (kt == kt0 + 5) {      // split the wait from the barrier for the instrumented iteration
+      if (PD >= 3 && wait_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      else if (PD >= 2 && wait_tiles >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ISTAMP(1);
+    }
+#endif
+    if (PD >= 3 && wait_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+    else if (PD >= 2 && wait_tiles >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + PD < kt1) {
+#ifdef CCLIP_GEMM_STAMPS
+    if (kt == kt0) STAMP(3);
+#endif
+    ISTAMP(2);
+    if (DMA && !ILV && !ILV_EARLY) {
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
       stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);
     }
     const char* At = smem + cur * STAGE_BYTES_ + a_off;
     const char* Bt = smem + cur * STAGE_BYTES_ + NSA * TILE_BYTES + b_off;
@@ -176,12 +306,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
       wf[0][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 0, lane) : frag_cols<1>(Bt, b_row, nt, 0, lane);
+    if (DMA && ILV_EARLY) {   // program order: k-step 0 reads, DMA, k-step 1 reads
+      int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
+      char* sb = smem + ns * STAGE_BYTES_;
+      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
+      stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       xf[1][mt] = A_KC ? frag_rows(At, a_row + 16 * mt, 1, lane) : frag_cols<0>(At, a_row, mt, 1, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
       wf[1][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 1, lane) : frag_cols<1>(Bt, b_row, nt, 1, lane);
+    if (DMA && ILV) {     // after the fragment reads in program order (the DMA writes LDS: the reads may not sink below it)
+      int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
+      char* sb = smem + ns * STAGE_BYTES_;
+      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
+      stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
+    }
+    ISTAMP(3);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -190,85 +333,57 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
         for (int nt = 0; nt < 4; ++nt)
           acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
     }
-    // schedule: 8 DS reads (k-step 0) up front, then 2 MFMA : 1 DS read while k-step 1's fragments stream in
+    // schedule: the LDS reads of k-step 0 up front; k-step 1's fragments stream in between k-step 0's MFMAs; the DMA
+    // instructions of tile kt+PD go between k-step 1's MFMAs
     constexpr int RD = (A_KC ? MT : 2 * MT) + (B_KC ? 4 : 8);     // LDS read instructions per k-step
     constexpr int NM = 4 * MT;                                    // MFMAs per k-step
     __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+    if (DMA && ILV_EARLY) {
 #pragma unroll
-    for (int i = 0; i < RD; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NM / RD > 0 ? NM / RD : 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int i = 0; i < G; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / RD > 0 ? NM / RD : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    if (DMA && ILV) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / G > 0 ? NM / G : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
+#ifdef CCLIP_GEMM_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    ISTAMP(4);
+#endif
     cur = cur + 1 == STAGES ? 0 : cur + 1;
-  }
+  };
+  int kt = kt0;
+  for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, PD - 1);
+  for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, kt1 - 1 - kt);
 
+  STAMP(4);
   // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
   // Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then the
   // math and the stores - one memory round trip per batch instead of one per 8-column run.
-  const int li = lane & 15, g = lane >> 4;
-  float bsv[2][8];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int n0 = bn0 + wn0 + 32 * h + 8 * g;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) bsv[h][r] = 0.f;
-    if (p.bias && !p.split_ws && n0 < p.N) {
-      if (n0 + 8 <= p.N) {
-        const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
-        bsv[h][0] = b0.x; bsv[h][1] = b0.y; bsv[h][2] = b0.z; bsv[h][3] = b0.w;
-        bsv[h][4] = b1.x; bsv[h][5] = b1.y; bsv[h][6] = b1.z; bsv[h][7] = b1.w;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) if (n0 + r < p.N) bsv[h][r] = p.bias[n0 + r];
-      }
-    }
-  }
-  constexpr int EB = MT >= 8 ? 2 : 4;                      // m-tiles per epilogue batch (register budget)
-  constexpr bool HAS_AUX = ACT >= CCLIP_ACT_DQUICKGELU;
+  if (!PRE) epi_bias(p, bn0 + wn0, g, bsv);
 #pragma unroll
   for (int mb = 0; mb < MT; mb += EB) {
-    float rres[EB][2][8];
-    float raux[HAS_AUX ? EB : 1][2][8];
-    // pass 1: loads
-#pragma unroll
-    for (int mi = 0; mi < EB; ++mi) {
-      const int m = bm0 + wm0 + 16 * (mb + mi) + li;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int n0 = bn0 + wn0 + 32 * h + 8 * g;
-        const bool live = m < p.M && n0 < p.N && !p.split_ws;
-        const bool full = n0 + 8 <= p.N;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) rres[mi][h][r] = 0.f;
-        if (live && p.residual) {
-          const float* rp = p.residual + (long)m * p.ldr + n0;
-          if (full) {
-            const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
-            rres[mi][h][0] = r0.x; rres[mi][h][1] = r0.y; rres[mi][h][2] = r0.z; rres[mi][h][3] = r0.w;
-            rres[mi][h][4] = r1.x; rres[mi][h][5] = r1.y; rres[mi][h][6] = r1.z; rres[mi][h][7] = r1.w;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) rres[mi][h][r] = rp[r];
-          }
-        }
-        if (HAS_AUX) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) raux[HAS_AUX ? mi : 0][h][r] = 0.f;
-          if (live) {
-            const bf16* ap = p.aux + (long)m * p.ldaux + n0;
-            if (full) {
-              const bf16x8 ax = *(const bf16x8*)ap;
-#pragma unroll
-              for (int r = 0; r < 8; ++r) raux[HAS_AUX ? mi : 0][h][r] = (float)ax[r];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 8; ++r) if (n0 + r < p.N) raux[HAS_AUX ? mi : 0][h][r] = (float)ap[r];
-            }
-          }
-        }
-      }
-    }
+    // pass 1: loads (already in flight since kernel start when PRE)
+    if (!PRE) epi_loads<EB, HAS_AUX, true, true>(p, bm0 + wm0, bn0 + wn0, mb, li, g, rres, raux);
+    else if (HAS_AUX) epi_loads<EB, HAS_AUX, true, false>(p, bm0 + wm0, bn0 + wn0, mb, li, g, rres, raux);
     // pass 2: math + stores
 #pragma unroll
     for (int mi = 0; mi < EB; ++mi) {
@@ -304,7 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
         }
         if (ACT != CCLIP_ACT_NONE) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], raux[HAS_AUX ? mi : 0][h][r]);
+          for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], (float)raux[HAS_AUX ? mi : 0][h][r]);
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += rres[mi][h][r];
@@ -333,6 +448,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       }
     }
   }
+  STAMP(5);
+#ifdef CCLIP_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(6);
+#endif
 }
 
 // launcher for one tile configuration; instantiates exactly the (layout, activation) pairs the hot path issues
