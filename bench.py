@@ -39,6 +39,18 @@ CAPTION_FWD_FLOPS = 16_420_000_000 + 243_793_920   # GPT-2 prefix forward at S=8
 PEAK_BF16 = 2.5e15                       # dense bf16 MFMA, MI355X_MICROARCH.md
 
 
+def tower_flops(geo):
+    """Algorithmic forward FLOPs (2*MAC, GEMM-class work, no causal discount) per image / per caption, SURVEY.md 8d's
+    accounting: ViT-B/32 -> 8 817 623 040 and 5 959 540 736; ViT-L/14@336px -> 381 919 789 056 per image."""
+    def layers(T, W, L):
+        return L * (24 * T * W * W + 4 * T * T * W)
+    T, W = geo.vision_tokens, geo.vision_width
+    img = 2 * (T - 1) * 3 * geo.vision_patch_size ** 2 * W + layers(T, W, geo.vision_layers) + 2 * W * geo.embed_dim
+    Tt, Wt = geo.context_length, geo.transformer_width
+    txt = layers(Tt, Wt, geo.transformer_layers) + 2 * Wt * geo.embed_dim
+    return img, txt
+
+
 def host_cores() -> int:
     """CPU share this process may actually use: min(affinity mask, cgroup quota, 16 = one GPU's share of the box)."""
     n = os.cpu_count() or 1
@@ -334,9 +346,10 @@ def main():
     if rank == 0:
         pairs = B * world * args.steps
         value = pairs / dt
-        step_flops = (IMAGE_FWD_FLOPS if args.mode == "image" else PAIR_FWD_FLOPS * (3 if args.mode == "train" else 1)) * B
+        img_fl, txt_fl = tower_flops(geo)
+        step_flops = (img_fl if args.mode == "image" else (img_fl + txt_fl) * (3 if args.mode == "train" else 1)) * B
         out = {
-            "metric": ("images/sec encode_image ViT-B/32 bs=1024" if args.mode == "image"
+            "metric": (f"images/sec encode_image {args.model} bs={B}" if args.mode == "image"
                        else "image-text pairs/sec (encode+logits) ViT-B/32 bs=1024 at 1/2/4/8 MI355X"),
             "value": round(value, 1), "unit": "images/s" if args.mode == "image" else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -344,7 +357,7 @@ def main():
             "config": {"workload": ("CLIP/train.py contrastive fine-tune step (fwd+bwd+AdamW)" if args.mode == "train"
                                     else "encode_image forward only" if args.mode == "image"
                                     else "encode_image+encode_text+logits forward only") + f", {args.model}, bs={B}/GPU, "
-                       "224x224 N(0,1) images + 77-token captions, seeded synthetic weights",
+                       f"{geo.image_resolution}x{geo.image_resolution} N(0,1) images + 77-token captions, seeded synthetic weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "mode": args.mode},
             "step_mfu_bf16": round(step_flops * world / (dt / args.steps) / (PEAK_BF16 * world), 4),
             "loss": round(loss_val, 5),

@@ -218,11 +218,21 @@ class CLIP(nn.Module):
         if tuple(image.shape[1:]) != (3, geo.image_resolution, geo.image_resolution):
             raise RuntimeError(f"encode_image: expected [N,3,{geo.image_resolution},{geo.image_resolution}], got {tuple(image.shape)}")
         M = B * T
+        if train and T > 128:
+            raise NotImplementedError(f"{T}-token image tower: the attention backward kernel covers T <= 128 (ViT-B/32); "
+                                      "longer sequences are forward-only (encode_image) in this build")
         img = image.detach().to(torch.float32).contiguous()
-        patches = torch.empty(M, 3 * P * P, device=dev, dtype=self.compute_dtype)
+        KP = 3 * P * P
+        KPAD = (KP + 7) // 8 * 8                   # P = 14: 588 -> 592, rows stay 16-byte aligned for the GEMM's DMA
+        patches = torch.empty(M, KPAD, device=dev, dtype=self.compute_dtype)
         ops.patchify(img, patches, P)
+        w16 = ar.b["visual.conv1.weight"].view(D, KP)
+        if KPAD != KP:
+            wp = torch.zeros(D, KPAD, device=dev, dtype=self.compute_dtype)
+            wp[:, :KP].copy_(w16)
+            w16 = wp
         patch_out = torch.empty(M, D, device=dev, dtype=torch.float32)
-        ops.gemm_bf16(patches, ar.b["visual.conv1.weight"].view(D, -1), out_f32=patch_out)
+        ops.gemm_bf16(patches, w16, out_f32=patch_out)
         p = ar.params
         saved = st.alloc_saved(B, dev) if train else None
         x = saved["xs"][0, 0] if train else torch.empty(M, D, device=dev, dtype=torch.float32)

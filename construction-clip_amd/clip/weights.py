@@ -57,6 +57,8 @@ MODELS: Dict[str, CLIPGeometry] = {
     # small geometries for tests (same code path, seconds on CPU)
     "test-tiny": CLIPGeometry(64, 64, 2, 128, 32, 16, 512, 128, 2, 2),
     "test-small": CLIPGeometry(128, 96, 3, 256, 32, 24, 1024, 192, 3, 2),
+    # patch 14 (3*14*14 = 588 is not a multiple of 8) and 145 image tokens (> 128): the ViT-L/14 code path at toy size
+    "test-long": CLIPGeometry(64, 168, 2, 128, 14, 16, 512, 128, 2, 2),
 }
 
 

@@ -1,4 +1,5 @@
-// Fused multi-head attention (dh = 64, T <= 128) forward and backward for gfx950.
+// Fused multi-head attention (dh = 64) for gfx950: forward for any T (single-pass for T <= 128, key-block-tiled online
+// softmax beyond), backward for T <= 128.
 //
 // Replaces the scaled-dot-product core of nn.MultiheadAttention inside the `clip` package's
 // ResidualAttentionBlock (image tower: T=50 no mask; text tower: T=77 additive causal mask),
@@ -273,12 +274,114 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward for sequences longer than 128 (ViT-B/16: 197, ViT-L/14: 257, ViT-L/14@336px: 577 tokens): same S^T = K Q^T /
+// O^T = V^T P^T formulation, tiled over 64-key blocks with the online-softmax recurrence.  One workgroup per
+// (batch, head, 64-query block); wave w owns queries 16w..16w+15 of the block; a K block and a V block (8 KiB each)
+// are staged per step.  Causal workgroups stop at their own diagonal block.
+__global__ __launch_bounds__(256) void attn_long_fwd_kernel(const AttnArgs a, int nqb) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+  char* Ks = smem;
+  char* Vs = smem + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+  const int b = bh / a.H, h = bh % a.H;
+  const int T = a.T;
+  const long row0 = (long)b * T;
+  const int qi = 64 * qb + 16 * wave + li;
+  const int qrow = qi < T ? qi : T - 1;
+  const bf16* qp = a.q + (row0 + qrow) * a.ldq + h * 64 + 8 * g;
+  const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+  const float NEG = -__builtin_inff();
+  float m = NEG, l = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int nkb = (T + 63) >> 6;
+  if (a.causal && qb + 1 < nkb) nkb = qb + 1;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();                                   // every wave is done with the previous blocks
+    for (int idx = tid; idx < 64 * 8; idx += 256) {
+      const int row = idx >> 3, c = idx & 7, key = 64 * kb + row;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (key < T) {
+        kv = *(const uint4*)(a.k + (row0 + key) * a.ldk + h * 64 + c * 8);
+        vv = *(const uint4*)(a.v + (row0 + key) * a.ldv + h * 64 + c * 8);
+      }
+      *(uint4*)(Ks + at_off(row, c)) = kv;
+      *(uint4*)(Vs + at_off(row, c)) = vv;
+    }
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      s[kt] = CCLIP_MFMA_16x16x32(frag_row(Ks, 16 * kt + li, g), qf0, s[kt]);
+      s[kt] = CCLIP_MFMA_16x16x32(frag_row(Ks, 16 * kt + li, 4 + g), qf1, s[kt]);
+    }
+    float bm = NEG;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 64 * kb + 16 * kt + 4 * g + r;
+        bool ok = key < T && (!a.causal || key <= qi);
+        if (ok && a.keep) ok = a.keep[row0 + key] != 0.f;
+        const float val = ok ? s[kt][r] * a.scale : NEG;
+        s[kt][r] = val;
+        bm = fmaxf(bm, val);
+      }
+    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);
+    const float msafe = mn == NEG ? 0.f : mn;
+    const float alpha = __expf(m - msafe);             // m = -inf (nothing seen yet) -> 0
+    float bl = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(s[kt][r] - msafe);
+        s[kt][r] = pv;
+        bl += pv;
+      }
+    bl += __shfl_xor(bl, 16, 64);
+    bl += __shfl_xor(bl, 32, 64);
+    l = l * alpha + bl;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { pf[j] = (bf16)s[2 * ss][j]; pf[4 + j] = (bf16)s[2 * ss + 1][j]; }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = CCLIP_MFMA_16x16x32(frag_tr(Vs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, o[dt]);
+    }
+  }
+  if (qi < T) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    bf16* op = a.o + (row0 + qi) * a.ldo + h * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+      *(bf16x4*)(op + 16 * dt) = ov;
+    }
+    if (g == 0 && a.lse) a.lse[((long)b * a.H + h) * T + qi] = (m == NEG ? 0.f : m) + __logf(l);
+  }
+}
+
 }  // namespace CCLIP_NS
 using namespace CCLIP_NS;
 
 static bool attn_args_ok(const cclip_attn_desc* d, bool bwd) {
   if (!d || !d->q || !d->k || !d->v || !d->o) return false;
-  if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->T > 128 || d->head_dim != 64) return false;
+  if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->T > (bwd ? 128 : 8192) || d->head_dim != 64) return false;
   if ((d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7)) return false;
   if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->o) & 15) return false;
   if (bwd) {
@@ -306,6 +409,11 @@ extern "C" int CCLIP_FN(cclip_attention_fwd)(const cclip_attn_desc* d, hipStream
   const AttnArgs a = attn_pack(d);
   dim3 grid(d->B * d->H), block(256);
   const int nkt = (d->T + 15) / 16;
+  if (d->T > 128) {
+    const int nqb = (d->T + 63) / 64;
+    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(d->B * d->H * nqb), block, 0, stream, a, nqb);
+    return cclip_launch_status();
+  }
   if (nkt <= 2) hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, block, 0, stream, a);
   else if (nkt <= 4) hipLaunchKernelGGL((attn_fwd_kernel<4>), grid, block, 0, stream, a);
   else if (nkt <= 5) hipLaunchKernelGGL((attn_fwd_kernel<5>), grid, block, 0, stream, a);

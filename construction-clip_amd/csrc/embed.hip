@@ -38,6 +38,35 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   }
 }
 
+// any patch size (ViT-L/14: P = 14, 3*P*P = 588): rows are zero-padded to KPAD = round_up(3*P*P, 8) elements so that
+// the im2col matrix keeps 16-byte rows for the GEMM's DMA; element-wise gather (4-byte reads)
+__global__ __launch_bounds__(256) void patchify_any_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B,
+                                                           int R, int P, int G) {
+  const int T = G * G + 1, KP = 3 * P * P, chunks = (KP + 7) / 8, KPAD = chunks * 8;
+  const long total = (long)B * T * chunks;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int ch = (int)(i % chunks);
+    const long row = i / chunks;
+    const int t = (int)(row % T);
+    const long b = row / T;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+    if (t != 0) {
+      const int p = t - 1, py = p / G, px = p % G;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = ch * 8 + j;
+        if (k < KP) {
+          const int c = k / (P * P), rem = k % (P * P), ky = rem / P, kx = rem % P;
+          o[j] = (bf16)img[(((b * 3 + c) * R) + (py * P + ky)) * (long)R + px * P + kx];
+        }
+      }
+    }
+    *(bf16x8*)(out + row * KPAD + ch * 8) = o;
+  }
+}
+
 // one wave per token row: x0 = patch_out[row] + pos[t] (+ cls if t == 0); LayerNorm(x0) -> x
 template <int NV>
 __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* __restrict__ patch_out,
@@ -243,11 +272,12 @@ using namespace CCLIP_NS;
 static int grid_rows4(int rows) { int g = (rows + 3) / 4; return g > 4096 ? 4096 : (g < 1 ? 1 : g); }
 
 extern "C" int CCLIP_FN(cclip_patchify)(const float* image, void* out_bf16, int32_t B, int32_t R, int32_t P, hipStream_t stream) {
-  if (!image || !out_bf16 || B <= 0 || P <= 0 || R % P || (P & 7) || ((uintptr_t)image & 15)) return CCLIP_ERR_ARG;
+  if (!image || !out_bf16 || B <= 0 || P <= 0 || R % P || ((uintptr_t)image & 15) || ((uintptr_t)out_bf16 & 15)) return CCLIP_ERR_ARG;
   const int G = R / P;
-  const long total = (long)B * (G * G + 1) * (3 * P * P / 8);
+  const long total = (long)B * (G * G + 1) * ((3 * P * P + 7) / 8);
   long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(patchify_kernel, dim3((int)blocks), dim3(256), 0, stream, image, (bf16*)out_bf16, B, R, P, G);
+  if (P & 7) hipLaunchKernelGGL(patchify_any_kernel, dim3((int)blocks), dim3(256), 0, stream, image, (bf16*)out_bf16, B, R, P, G);
+  else hipLaunchKernelGGL(patchify_kernel, dim3((int)blocks), dim3(256), 0, stream, image, (bf16*)out_bf16, B, R, P, G);
   return cclip_launch_status();
 }
 

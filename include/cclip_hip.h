@@ -100,8 +100,9 @@ int cclip_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const 
                         void* dx_out_bf16, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                         float* ws, hipStream_t stream);
 
-/* ---- fused multi-head attention, head_dim 64, T <= 128 ---------------------------------------
- * Replaces softmax(q k^T * scale + mask) v of nn.MultiheadAttention (CLIP towers; causal for the
+/* ---- fused multi-head attention, head_dim 64; forward any T <= 8192, backward T <= 128 -------
+ * (T > 128 - ViT-B/16 197, ViT-L/14 257, ViT-L/14@336px 577 tokens - runs the key-block-tiled
+ * online-softmax forward.)  Replaces softmax(q k^T * scale + mask) v of nn.MultiheadAttention (CLIP towers; causal for the
  * text tower) and of GPT-2 (causal + key padding).  q/k/v/o/d*: bf16, row (b*T + t), head h at
  * column h*64 of the given base pointer (so a packed [B*T, 3D] qkv buffer is passed as three
  * offset pointers with the same row stride).  lse: fp32 [B,H,T] written by fwd, read by bwd.
@@ -137,7 +138,9 @@ int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int
 
 /* ---- embeddings ------------------------------------------------------------------------------
  * cclip_patchify: image fp32 [B,3,R,R] -> bf16 im2col [B*T, 3*P*P], T = (R/P)^2 + 1, class slot
- *   row (t = 0) zero; column order (c, ky, kx) = conv1.weight.view(W,-1).  P % 8 == 0.
+ *   row (t = 0) zero; column order (c, ky, kx) = conv1.weight.view(W,-1).  When 3*P*P is not a
+ *   multiple of 8 (P = 14: 588) rows are zero-padded to round_up(3*P*P, 8) elements (592) so they stay
+ *   16-byte aligned for the GEMM; pad the weight rows the same way.
  *   Replaces the input side of VisionTransformer.conv1 (k = s = P, no bias).
  * cclip_vit_embed_ln: x0 = patch_out + positional_embedding[t] (+ class_embedding at t = 0),
  *   x = ln_pre(x0); optional saves x0, mean, rstd.  All fp32 [rows = B*T, D].

@@ -70,6 +70,16 @@ def clip_case(name: str, n: int, seed: int, with_grads: bool):
     return out
 
 
+def image_only_case(name: str, n: int, seed: int):
+    """encode_image alone (BASELINE.json configs[4]: ViT-L/14@336px; 577 tokens, patch 14)."""
+    geo = MODELS[name]
+    sd = init_state_dict(geo, seed)
+    img = synthetic_images(n, geo, seed + 1)
+    with torch.no_grad():
+        feat = O.encode_image(sd, img)
+    return dict(model=name, seed=seed, n=n, image_features=feat)
+
+
 def caption_case(name: str, b: int, lc: int, seed: int):
     geo = GPT2_MODELS[name]
     sd = init_caption_state_dict(geo, seed)
@@ -114,6 +124,8 @@ def main():
     torch.save(clip_case("test-tiny", 9, 11, True), os.path.join(OUT, "clip_test_tiny.pt"))
     torch.save(clip_case("test-small", 9, 12, True), os.path.join(OUT, "clip_test_small.pt"))
     torch.save(clip_case("ViT-B/32", 9, 567, False), os.path.join(OUT, "clip_vit_b32.pt"))
+    torch.save(clip_case("test-long", 9, 13, False), os.path.join(OUT, "clip_test_long.pt"))
+    torch.save(image_only_case("ViT-L/14@336px", 2, 567), os.path.join(OUT, "clip_vit_l14_336.pt"))
     torch.save(caption_case("test-tiny", 3, 12, 21), os.path.join(OUT, "caption_test_tiny.pt"))
     torch.save(caption_tmapper_case("test-tiny", 3, 12, 23, clip_length=6, num_layers=2), os.path.join(OUT, "caption_tmapper_tiny.pt"))
     for f in sorted(os.listdir(OUT)):

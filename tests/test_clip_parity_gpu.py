@@ -57,7 +57,7 @@ def _argmax_agrees(got, ref, dim, logit_tol=LOGIT_TOL):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("fix", ["clip_test_tiny.pt", "clip_test_small.pt", "clip_vit_b32.pt"])
+@pytest.mark.parametrize("fix", ["clip_test_tiny.pt", "clip_test_small.pt", "clip_vit_b32.pt", "clip_test_long.pt"])
 def test_forward_matches_golden(fix, dtype):
     g, model, img, txt = _setup(fix, dtype)
     t = TOL[dtype]
@@ -83,6 +83,26 @@ def test_forward_matches_golden(fix, dtype):
     if dtype == torch.float16:      # CLIP/predict.py:54, parse_coco.py:47,52: the predicted class index
         assert torch.equal(l2.softmax(-1).argmax(1).cpu(), g["zs2_idx"])
         assert torch.equal(l9.softmax(-1).argmax(1).cpu(), g["zs9_idx"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vit_l14_336_encode_image(dtype):
+    """BASELINE.json configs[4] geometry: ViT-L/14@336px (patch 14 -> 588-element rows padded to 592, 577 tokens -> tiled
+    online-softmax attention, width 1024, 24 layers) against the oracle's features for 2 images."""
+    import clip
+    from clip.weights import MODELS, init_state_dict, synthetic_images
+    g = torch.load(os.path.join(GOLD, "clip_vit_l14_336.pt"), weights_only=True)
+    geo = MODELS[g["model"]]
+    assert (geo.vision_tokens, geo.vision_patch_size, geo.vision_width, geo.vision_layers) == (577, 14, 1024, 24)
+    model = clip.build_model(init_state_dict(geo, g["seed"]), dtype).cuda()
+    img = synthetic_images(g["n"], geo, g["seed"] + 1).cuda()
+    with torch.no_grad():
+        fi = model.encode_image(img)
+    assert fi.shape == (g["n"], 768)
+    assert rel(fi, g["image_features"]) < TOL[dtype]["feat"], rel(fi, g["image_features"])
+    with pytest.raises(NotImplementedError):           # forward-only beyond 128 tokens: says so instead of a wrong gradient
+        model.train()
+        model(img, torch.zeros(g["n"], geo.context_length, dtype=torch.int64, device="cuda"))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -87,20 +87,26 @@ def test_layernorm_row_index():
     close("ln scatter dx", dx, xr.grad, 1e-4, 1e-5)
 
 
-def _attn_ref(q, k, v, causal, keep):
-    # q,k,v: [B,H,T,64] fp32
+def _attn_scores(q, k, causal, keep):
     s = (q @ k.transpose(-1, -2)) * 0.125
     T = q.shape[2]
     if causal:
         s = s + torch.full((T, T), float("-inf"), device=q.device).triu_(1)
     if keep is not None:
         s = s.masked_fill(keep[:, None, None, :] == 0, float("-inf"))
-    return torch.softmax(s, dim=-1) @ v
+    return s
+
+
+def _attn_ref(q, k, v, causal, keep):
+    # q,k,v: [B,H,T,64] fp32
+    return torch.softmax(_attn_scores(q, k, causal, keep), dim=-1) @ v
 
 
 @pytest.mark.parametrize("B,T,H,causal,pad", [(3, 50, 12, False, False), (2, 77, 8, True, False), (2, 5, 2, False, False),
                                               (3, 80, 12, True, True), (1, 128, 3, True, False), (2, 33, 2, False, True),
-                                              (2, 17, 1, True, False), (1, 100, 2, False, False)])
+                                              (2, 17, 1, True, False), (1, 100, 2, False, False),
+                                              (2, 129, 2, False, False), (1, 197, 3, True, False), (2, 257, 2, False, True),
+                                              (1, 577, 4, False, False), (1, 300, 1, True, True)])
 def test_attention_fwd_bwd(B, T, H, causal, pad):
     o = ops()
     g = G(B * 1000 + T)
@@ -119,6 +125,13 @@ def test_attention_fwd_bwd(B, T, H, causal, pad):
     ref = _attn_ref(f[0], f[1], f[2], causal, keep)            # [B,H,T,64]
     ref2 = ref.permute(0, 2, 1, 3).reshape(B * T, D)
     close("attn fwd", out, ref2, 1.5e-2)
+    close("attn lse", lse, torch.logsumexp(_attn_scores(f[0], f[1], causal, keep), dim=-1), 1e-3, 2e-3)
+    if T > 128:        # longer sequences: forward only (tiled online softmax); backward is refused, not wrong
+        from cclip_hip._lib import CclipError
+        dq = torch.empty_like(qkv)
+        with pytest.raises(CclipError):
+            o.attention_bwd(q, k, v, out, lse, out, dq[:, :D], dq[:, D:2 * D], dq[:, 2 * D:], B=B, T=T, H=H, causal=causal, key_keep=keep)
+        return
     dout = torch.randn(B * T, D, device="cuda", generator=g).bfloat16()
     dqkv = torch.full((B * T, 3 * D), float("nan"), device="cuda", dtype=torch.bfloat16)
     o.attention_bwd(q, k, v, out, lse, dout, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B=B, T=T, H=H, causal=causal,
@@ -183,6 +196,22 @@ def test_gemm_f32(M, N, K, ta, tb):
     ref = 0.5 * (Av.double() @ Bv.double().t()) + 2.0 * C.double()
     o.gemm_f32(Av, Bv, C, alpha=0.5, beta=2.0)
     close("gemm_f32", C, ref.float(), 2e-6 * math.sqrt(K) + 1e-6)
+
+
+@pytest.mark.parametrize("P,grid", [(14, 3), (14, 24), (16, 2), (6, 4)])
+def test_patchify_any_patch_size(P, grid):
+    """ViT-L/14: 3*14*14 = 588 is not a multiple of 8 -> rows zero-padded to 592; bit-exact against unfold."""
+    o = ops()
+    R, B = P * grid, 2
+    img = torch.randn(B, 3, R, R, device="cuda", generator=G(P * 100 + grid))
+    KP = 3 * P * P
+    KPAD = (KP + 7) // 8 * 8
+    out = torch.full((B * (grid * grid + 1), KPAD), float("nan"), device="cuda", dtype=torch.bfloat16)
+    o.patchify(img, out, P)
+    ref = torch.nn.functional.unfold(img, kernel_size=P, stride=P).transpose(1, 2)          # [B, grid*grid, 3*P*P] in (c, ky, kx) order
+    got = out.view(B, grid * grid + 1, KPAD)
+    assert torch.equal(got[:, 1:, :KP], ref.bfloat16())
+    assert (got[:, 0] == 0).all() and (got[:, :, KP:] == 0).all()
 
 
 def test_patchify_and_embeds():
