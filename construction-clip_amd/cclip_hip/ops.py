@@ -298,6 +298,20 @@ def attention_small_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H:
     check(_fn("cclip_attention_small_bwd", q, k, v, o, dout, dq, dk, dv)(ctypes.byref(d), _stream()), "cclip_attention_small_bwd")
 
 
+def attention_decode(q, kcache, vcache, out, *, H: int, S: int, scale=None) -> None:
+    """One new query per sequence against its KV cache.  q/out: [B, H*64] 16-bit rows (any row stride); kcache/vcache:
+    [B, Smax, H*64] views (position stride = stride(1), sequence stride = stride(0)); S = cached positions incl. the new one."""
+    for t, n in ((q, "q"), (kcache, "kcache"), (vcache, "vcache"), (out, "out")):
+        _req16(t, n)
+        assert t.stride(-1) == 1
+    B = q.shape[0]
+    assert kcache.dim() == 3 and vcache.shape == kcache.shape and kcache.stride() == vcache.stride() and S <= kcache.shape[1]
+    check(_fn("cclip_attention_decode", q, kcache, vcache, out)(
+        _p(q), c_long(q.stride(0)), _p(kcache), _p(vcache), c_long(kcache.stride(1)), c_long(kcache.stride(0)), _p(out),
+        c_long(out.stride(0)), c_int(B), c_int(H), c_int(S), c_float(64 ** -0.5 if scale is None else scale), _stream()),
+        "cclip_attention_decode")
+
+
 # --------------------------------------------------------------------------------------------
 # exact fp32 GEMM:  C = alpha * A @ B^T-like contraction with arbitrary strides
 # --------------------------------------------------------------------------------------------

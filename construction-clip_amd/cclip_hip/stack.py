@@ -110,9 +110,11 @@ class BlockStack:
             out=torch.empty(M, D, device=device, dtype=torch.float32), B=B, key_keep=None)
 
     def forward(self, x: torch.Tensor, B: int, *, saved: Optional[dict] = None,
-                key_keep: Optional[torch.Tensor] = None, T: Optional[int] = None) -> torch.Tensor:
+                key_keep: Optional[torch.Tensor] = None, T: Optional[int] = None, kv_out=None) -> torch.Tensor:
         """x: fp32 [B*T, D] residual stream entering block 0; returns the stream leaving the last block.
-        saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0]."""
+        saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0].
+        kv_out = (kcache, vcache), each [L, B, Smax, D] 16-bit: every layer's keys / values of positions [0, T) are
+        kept there (prefill of the KV-cached decode, see decode_step)."""
         geo = self.geo
         D, H = geo.width, geo.heads
         Hd = geo.hidden or 4 * D
@@ -144,6 +146,9 @@ class BlockStack:
                 m1 = r1 = m2 = r2 = lse_l = None
             ops.layernorm_fwd(x_in, w.ln1_w, w.ln1_b, rows=M, out_bf16=xn1, mean=m1, rstd=r1)
             ops.gemm_bf16(xn1, w.w_qkv, b_kcontig=kc, bias=w.b_qkv, out_bf16=qkv, M=M)
+            if kv_out is not None:       # data movement only
+                kv_out[0][l, :B, :T].copy_(qkv[:M, D:2 * D].view(B, T, D))
+                kv_out[1][l, :B, :T].copy_(qkv[:M, 2 * D:3 * D].view(B, T, D))
             if geo.head_dim == 64:
                 ops.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H, causal=geo.causal,
                                   key_keep=key_keep, lse=lse_l)
@@ -156,6 +161,32 @@ class BlockStack:
             ops.gemm_bf16(xn2, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, out_pre=h, M=M)
             ops.gemm_bf16(g, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=x_mid, out_f32=x_out, M=M)
             x = x_out
+        return x
+
+    # ------------------------------------------------------------------ KV-cached decode
+    def decode_step(self, x: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, pos: int) -> torch.Tensor:
+        """One token per sequence: x fp32 [nb, D] is the residual stream of the token at position `pos` (updated in place and
+        returned); kcache / vcache [L, nb, Smax, D] hold positions [0, pos) and receive this token's keys / values.
+        Same arithmetic as forward() restricted to the last row of a causal sequence (no key padding)."""
+        geo = self.geo
+        D, H = geo.width, geo.heads
+        Hd = geo.hidden or 4 * D
+        assert geo.head_dim == 64 and geo.causal, "decode_step: GPT-2-shaped stacks only"
+        nb = x.shape[0]
+        kc = geo.linear_layout
+        dev = x.device
+        bf = torch.empty(nb, 5 * D + Hd, device=dev, dtype=self.dtype)          # xn | qkv | a | g
+        xn, qkv, a, g = bf[:, 0:D], bf[:, D:4 * D], bf[:, 4 * D:5 * D], bf[:, 5 * D:5 * D + Hd]
+        for l, w in enumerate(self.blocks):
+            ops.layernorm_fwd(x, w.ln1_w, w.ln1_b, rows=nb, out_bf16=xn)
+            ops.gemm_bf16(xn, w.w_qkv, b_kcontig=kc, bias=w.b_qkv, out_bf16=qkv, M=nb)
+            kcache[l, :nb, pos].copy_(qkv[:, D:2 * D])
+            vcache[l, :nb, pos].copy_(qkv[:, 2 * D:3 * D])
+            ops.attention_decode(qkv[:, 0:D], kcache[l, :nb], vcache[l, :nb], a, H=H, S=pos + 1)
+            ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x, out_f32=x, M=nb)
+            ops.layernorm_fwd(x, w.ln2_w, w.ln2_b, rows=nb, out_bf16=xn)
+            ops.gemm_bf16(xn, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, M=nb)
+            ops.gemm_bf16(g, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=x, out_f32=x, M=nb)
         return x
 
     # ------------------------------------------------------------------ backward

@@ -233,14 +233,59 @@ class GPT2LMHeadModel(_Holder):
             m.load_state_dict({k[len("model."):]: v for k, v in full.items() if k.startswith("model.")})
         return m
 
-    def forward(self, inputs_embeds=None, attention_mask=None, labels=None, input_ids=None, **kw):
+    def forward(self, inputs_embeds=None, attention_mask=None, labels=None, input_ids=None, past_key_values=None,
+                use_cache: bool = False, **kw):
+        """`.logits` of GPT2LMHeadModel(inputs_embeds=..., attention_mask=...).  With use_cache / past_key_values (a
+        KVCache) only the NEW positions are computed: prefill of a whole prefix when past_key_values is None, one
+        token per sequence afterwards (what HF's own use_cache does; the reference's generate loops never pass it and
+        recompute the full sequence every step, test.py:381)."""
         if self._owner is None:
             raise RuntimeError("GPT2LMHeadModel must be used as ClipCaptionModel.model")
         if labels is not None:
             raise NotImplementedError("labels= is never used by the reference's live code path (train.py:354 passes None)")
         if inputs_embeds is None:
             inputs_embeds = self.transformer.wte(input_ids)
+        if use_cache or past_key_values is not None:
+            if attention_mask is not None:
+                raise NotImplementedError("KV-cached decode: no key padding (the generate loops pass none)")
+            logits, cache = self._owner()._cached_logits(inputs_embeds, past_key_values)
+            return SimpleNamespace(logits=logits, past_key_values=cache)
         return SimpleNamespace(logits=self._owner()._logits_from_embeds(inputs_embeds, attention_mask))
+
+
+class KVCache:
+    """Per-layer keys / values of the positions processed so far: k, v [n_layer, n_seq, max_len, n_embd] in the
+    compute dtype, `length` positions valid.  reorder(idx) is beam search's `generated = generated[next_tokens_source]`
+    (test.py:416) applied to the cache."""
+
+    def __init__(self, n_layer: int, n_seq: int, max_len: int, width: int, device, dtype):
+        self.k = torch.empty(n_layer, n_seq, max_len, width, device=device, dtype=dtype)
+        self.v = torch.empty_like(self.k)
+        self.length = 0
+
+    @property
+    def n_seq(self) -> int:
+        return self.k.shape[1]
+
+    @property
+    def max_len(self) -> int:
+        return self.k.shape[2]
+
+    def reorder(self, idx: torch.Tensor) -> "KVCache":
+        idx = idx.to(self.k.device).long()
+        L = self.length
+        out = KVCache.__new__(KVCache)
+        out.k = torch.empty(self.k.shape[0], idx.numel(), *self.k.shape[2:], device=self.k.device, dtype=self.k.dtype)
+        out.v = torch.empty_like(out.k)
+        out.k[:, :, :L] = self.k[:, idx, :L]
+        out.v[:, :, :L] = self.v[:, idx, :L]
+        out.length = L
+        return out
+
+    def expand(self, n: int) -> "KVCache":
+        """one sequence -> n identical ones (`generated.expand(beam_size, ...)`, test.py:398)"""
+        assert self.n_seq == 1
+        return self.reorder(torch.zeros(n, dtype=torch.long))
 
 
 _GPT_KEYS = {"ln1_w": "ln_1.weight", "ln1_b": "ln_1.bias", "w_qkv": "attn.c_attn.weight", "b_qkv": "attn.c_attn.bias",
@@ -472,6 +517,36 @@ class ClipCaptionModel(nn.Module):
         xo = self._hidden_forward(x, B, S, attention_mask, None)
         rows = torch.arange(B * S, device=x.device, dtype=torch.int32)
         return self._lm_rows(xo, rows, False)[0].unflatten(0, (B, S))
+
+    def _cached_logits(self, inputs_embeds: torch.Tensor, cache: Optional[KVCache]):
+        """(logits [B, S_new, V], cache) for the new positions `inputs_embeds` [B, S_new, D] appended after cache.length."""
+        if torch.is_grad_enabled() and inputs_embeds.requires_grad:
+            raise NotImplementedError("KV-cached decode is inference only")
+        self._ensure_runtime()
+        self._arena.refresh_shadows()
+        g = self.model.geo
+        B, S, D = inputs_embeds.shape
+        dev = inputs_embeds.device
+        wpe = self._arena.params["model.transformer.wpe.weight"].data
+        emb = inputs_embeds.detach().float().contiguous()
+        if cache is None:                                     # prefill: the ordinary causal forward, keys / values kept
+            cache = KVCache(g.n_layer, B, g.n_positions, D, dev, self.compute_dtype)
+            x = torch.empty(B * S, D, device=dev, dtype=torch.float32)
+            ops.add_positional(emb.view(B * S, D), wpe, x, rows=B * S, S=S)
+            xo = self._stack.forward(x, B, T=S, kv_out=(cache.k, cache.v))
+            cache.length = S
+            rows = torch.arange(B * S, device=dev, dtype=torch.int32)
+            return self._lm_rows(xo, rows, False)[0].unflatten(0, (B, S)), cache
+        if S != 1 or B != cache.n_seq:
+            raise NotImplementedError(f"decode step takes one new token per cached sequence, got {tuple(inputs_embeds.shape)} for {cache.n_seq} sequences")
+        pos = cache.length
+        if pos >= cache.max_len:
+            raise RuntimeError(f"sequence longer than n_positions = {cache.max_len}")
+        x = emb.view(B, D) + wpe[pos]
+        xo = self._stack.decode_step(x, cache.k, cache.v, pos)
+        cache.length = pos + 1
+        rows = torch.arange(B, device=dev, dtype=torch.int32)
+        return self._lm_rows(xo, rows, False)[0].view(B, 1, -1), cache
 
     def _embed_and_run(self, tokens, prefix, attribute, mask, train: bool):
         self._ensure_runtime()

@@ -1,0 +1,66 @@
+// Decode-shaped attention: ONE new query per sequence against that sequence's cached keys / values (head_dim 64).
+//
+// The reference's generate_beam / generate2 (/root/reference/CLIP_prefix_caption/test.py:353-514, application.py:152-229)
+// call `model.gpt(inputs_embeds=generated)` on the whole, growing sequence at every step and keep only the last
+// position's logits - O(S^2) work per caption.  With a KV cache the step is one token wide; this kernel is its
+// softmax(q K^T * scale) V.  The new token attends to every cached position (its own included), so there is no mask.
+// Work per step is tiny (beams x heads workgroups, S <= 1024 keys) and bound by reading the cache once:
+// one wave per (sequence, head), fp32 math, K rows read as 128-byte rows per lane group, V rows coalesced.
+#include "cclip_common.h"
+#include "../../include/cclip_hip.h"
+
+namespace CCLIP_NS {
+
+#define DEC_MAXS 2048
+
+__global__ __launch_bounds__(64) void attn_decode_kernel(const bf16* __restrict__ q, long ldq, const bf16* __restrict__ kc,
+                                                         const bf16* __restrict__ vc, long ld_pos, long ld_seq,
+                                                         bf16* __restrict__ out, long ldo, int H, int S, float scale) {
+  __shared__ float p[DEC_MAXS];
+  __shared__ float qs[64];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  qs[lane] = (float)q[(long)b * ldq + h * 64 + lane];
+  __syncthreads();
+  const bf16* kb = kc + (long)b * ld_seq + h * 64;
+  const bf16* vb = vc + (long)b * ld_seq + h * 64;
+  float m = -__builtin_inff();
+  for (int key = lane; key < S; key += 64) {
+    const bf16* kr = kb + (long)key * ld_pos;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const bf16x8 kv = *(const bf16x8*)(kr + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += qs[8 * c + j] * (float)kv[j];
+    }
+    acc *= scale;
+    p[key] = acc;
+    m = fmaxf(m, acc);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  for (int key = lane; key < S; key += 64) {
+    const float e = __expf(p[key] - m);
+    p[key] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  __syncthreads();
+  float acc = 0.f;                                   // lane = output dimension
+  for (int key = 0; key < S; ++key) acc += p[key] * (float)vb[(long)key * ld_pos + lane];
+  out[(long)b * ldo + h * 64 + lane] = (bf16)(acc / l);
+}
+
+}  // namespace CCLIP_NS
+using namespace CCLIP_NS;
+
+extern "C" int CCLIP_FN(cclip_attention_decode)(const void* q, int64_t ldq, const void* kcache, const void* vcache, int64_t ld_pos,
+                                               int64_t ld_seq, void* out, int64_t ldo, int32_t B, int32_t H, int32_t S,
+                                               float scale, hipStream_t stream) {
+  if (!q || !kcache || !vcache || !out || B <= 0 || H <= 0 || S <= 0 || S > DEC_MAXS) return CCLIP_ERR_ARG;
+  if ((ld_pos & 7) || (ld_seq & 7) || (((uintptr_t)kcache | (uintptr_t)vcache) & 15)) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(64), 0, stream, (const bf16*)q, (long)ldq, (const bf16*)kcache,
+                     (const bf16*)vcache, (long)ld_pos, (long)ld_seq, (bf16*)out, (long)ldo, H, S, scale);
+  return cclip_launch_status();
+}

@@ -127,6 +127,15 @@ int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_small_fwd(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_small_bwd(const cclip_attn_desc* d, hipStream_t stream);
 
+/* Decode-shaped attention (head_dim 64): one new query per sequence against its KV cache - the step of the
+ * KV-cached replacement for the reference's generate_beam / generate2 loops, which re-run GPT-2 on the whole
+ * growing sequence every step (CLIP_prefix_caption/test.py:381,468; application.py:180).  q/out: [B, >= H*64]
+ * 16-bit; kcache/vcache: position s of sequence b at element offset b*ld_seq + s*ld_pos, head h at +h*64;
+ * S = number of cached positions INCLUDING the new token's own (<= 2048).  No mask (the newest token sees all). */
+int cclip_attention_decode(const void* q, int64_t ldq, const void* kcache, const void* vcache, int64_t ld_pos,
+                           int64_t ld_seq, void* out, int64_t ldo, int32_t B, int32_t H, int32_t S, float scale,
+                           hipStream_t stream);
+
 /* ---- exact fp32 GEMM (f32-input MFMA), generic strides ---------------------------------------
  * C[m*ldc+n] = alpha' * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m*ldc+n], with
  * alpha' = alpha * (alpha_log_dev ? exp(*alpha_log_dev) : 1)  (logit_scale.exp() without a host sync).
@@ -219,6 +228,9 @@ int cclip_attention_fwd_f16(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_bwd_f16(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_small_fwd_f16(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_small_bwd_f16(const cclip_attn_desc* d, hipStream_t stream);
+int cclip_attention_decode_f16(const void* q, int64_t ldq, const void* kcache, const void* vcache, int64_t ld_pos,
+                               int64_t ld_seq, void* out, int64_t ldo, int32_t B, int32_t H, int32_t S, float scale,
+                               hipStream_t stream);
 int cclip_patchify_f16(const float* image, void* out_f16, int32_t B, int32_t R, int32_t P, hipStream_t stream);
 int cclip_colsum_f16(const void* in, int32_t in_is_f16, int64_t ld, int32_t R, int32_t C, float* out,
                      int32_t accumulate, float* ws, hipStream_t stream);

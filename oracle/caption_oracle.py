@@ -125,3 +125,75 @@ def caption_loss(logits: Tensor, tokens: Tensor, prefix_length: int, attribute_l
     """train.py:356-357: logits[:, P+A-1:-1] vs tokens, CE with ignore_index=0."""
     lg = logits[:, prefix_length + attribute_length - 1: -1]
     return F.cross_entropy(lg.reshape(-1, lg.shape[-1]), tokens.flatten().long(), ignore_index=0)
+
+
+# ---- decoding (test.py:353-514), restated with a FULL forward per step exactly as the reference runs it -----------
+def _last_logits(sd: SD, generated: Tensor, n_head: int) -> Tensor:
+    return gpt2_forward(sd, generated, None, n_head)[:, -1, :]
+
+
+@torch.no_grad()
+def generate_beam_tokens(sd: SD, embed: Tensor, n_head: int, beam_size: int = 3, entry_length: int = 100,
+                         temperature: float = 0.5, stop_token: int = 102):
+    """generate_beam (test.py:353-441) up to the token / length / score tensors (no tokenizer).  Returns
+    (tokens [beams, steps], seq_lengths, scores / seq_lengths, per-step last-position logits of beam 0)."""
+    wte = sd["model.transformer.wte.weight"].float()
+    tokens, scores = None, None
+    seq_lengths = torch.ones(beam_size)
+    is_stopped = torch.zeros(beam_size, dtype=torch.bool)
+    generated = embed.float()
+    trace = []
+    for _ in range(entry_length):
+        raw = _last_logits(sd, generated, n_head)
+        trace.append(raw.clone())
+        logits = raw / (temperature if temperature > 0 else 1.0)
+        logits = logits.softmax(-1).log()
+        if scores is None:
+            scores, next_tokens = logits.topk(beam_size, -1)
+            generated = generated.expand(beam_size, *generated.shape[1:])
+            next_tokens, scores = next_tokens.permute(1, 0), scores.squeeze(0)
+            tokens = next_tokens
+        else:
+            logits[is_stopped] = -float("inf")
+            logits[is_stopped, 0] = 0
+            scores_sum = scores[:, None] + logits
+            seq_lengths[~is_stopped] += 1
+            scores_sum_average = scores_sum / seq_lengths[:, None]
+            scores_sum_average, next_tokens = scores_sum_average.view(-1).topk(beam_size, -1)
+            next_tokens_source = next_tokens // scores_sum.shape[1]
+            seq_lengths = seq_lengths[next_tokens_source]
+            next_tokens = (next_tokens % scores_sum.shape[1]).unsqueeze(1)
+            tokens = torch.cat((tokens[next_tokens_source], next_tokens), dim=1)
+            generated = generated[next_tokens_source]
+            scores = scores_sum_average * seq_lengths
+            is_stopped = is_stopped[next_tokens_source]
+        generated = torch.cat((generated, wte[next_tokens.squeeze(1)].view(generated.shape[0], 1, -1)), dim=1)
+        is_stopped = is_stopped + next_tokens.eq(stop_token).squeeze(1)
+        if is_stopped.all():
+            break
+    return tokens, seq_lengths, scores / seq_lengths, trace
+
+
+@torch.no_grad()
+def generate2_tokens(sd: SD, embed: Tensor, n_head: int, entry_length: int = 67, top_p: float = 0.8,
+                     temperature: float = 1.0, stop_token: int = 102):
+    """generate2 (test.py:443-514): nucleus filter, then arg-max.  Returns (tokens [1, steps], per-step logits)."""
+    wte = sd["model.transformer.wte.weight"].float()
+    generated = embed.float()
+    tokens, trace = None, []
+    for _ in range(entry_length):
+        raw = _last_logits(sd, generated, n_head)
+        trace.append(raw.clone())
+        logits = raw / (temperature if temperature > 0 else 1.0)
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        cumulative_probs = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
+        remove = cumulative_probs > top_p
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = 0
+        logits[:, sorted_indices[remove]] = -float("inf")
+        next_token = torch.argmax(logits, -1).unsqueeze(0)
+        tokens = next_token if tokens is None else torch.cat((tokens, next_token), dim=1)
+        generated = torch.cat((generated, wte[next_token]), dim=1)
+        if stop_token == next_token.item():
+            break
+    return tokens, trace
