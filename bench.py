@@ -111,7 +111,7 @@ def gemm_roofline(ev, nprof, traffic=None, traffic_src=None):
         t, fl, n = by.get(k, (0.0, 0.0, 0))
         by[k] = (t + e0.elapsed_time(e1), fl + f, n + 1)
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="gemm_bf16_kernel<*> (all layouts and tile configs)", achieved=round(ach, 1),
+    return dict(bound="mfma", kernel="gemm_bf16_kernel<*> + gemm_stream_kernel<*> (cclip_gemm_bf16: all layouts and tile configs)", achieved=round(ach, 1),
                 peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(ach * 1e12 / PEAK_BF16, 4), traffic=traffic,
                 traffic_unit="HBM-side bytes per launch (PMC, includes Infinity-Cache hits)", traffic_source=traffic_src,
                 flops_per_launch=round(tot_fl / max(len(ev), 1)),

@@ -63,11 +63,11 @@ def wgrad_splits(n_out: int, k_in: int, tokens: int) -> int:
 
 def wgrad_candidates(n_out: int, k_in: int, tokens: int):
     """(tile_config, split_k) candidates for the wgrad autotuner: aim the grid at 1x / 2x / 3x the machine's
-    concurrent workgroups (512 for the 128x128 tile, 256 for the 256x256 tile), >= 4 K-tiles per split."""
+    concurrent workgroups (512 for the 128x128 tile, 256 for the 256x128 and 256x256 tiles), >= 4 K-tiles per split."""
     nkt = (tokens + 63) // 64
     cands = []
-    for cfg, edge, slots in ((1, 128, 512), (3, 256, 256)):
-        tiles = ((n_out + edge - 1) // edge) * ((k_in + edge - 1) // edge)
+    for cfg, em, en, slots in ((1, 128, 128, 512), (2, 256, 128, 256), (3, 256, 256, 256)):
+        tiles = ((n_out + em - 1) // em) * ((k_in + en - 1) // en)
         for mult in (1, 2, 3):
             s = max(1, min(64, (slots * mult) // max(tiles, 1)))
             s = max(1, min(s, nkt // 4 if nkt >= 8 else 1))

@@ -166,3 +166,45 @@ def test_gemm_bad_args_raise():
     out = torch.zeros(64, 64, device="cuda")
     with pytest.raises(RuntimeError):
         ops.gemm_bf16(A, B, out_f32=out)
+
+
+# ---- tile configuration 4: persistent workgroups, epilogue streamed under the next tile's K loop ----------------------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,kind", [(512, 256, 768, "out16"), (2560, 384, 512, "gelu"), (1536, 256, 704, "gelu2"), (768, 128, 768, "res"),
+                                         (25600, 768, 640, "res"), (12800, 2304, 1000, "out16"), (256, 128, 2048, "res")])
+def test_gemm_streaming_config(M, N, K, kind, dt):
+    """Several tiles per workgroup (more tiles than CUs in the big cases), ragged K, all three epilogue modes; against fp32 torch."""
+    o = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(dt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    pre = A.float() @ B.float().t() + bias
+    if kind == "res":
+        x0 = torch.randn(M, N, device="cuda", generator=g)
+        x = x0.clone()
+        o.gemm_bf16(A, B, bias=bias, residual=x, out_f32=x, tile_config=4)
+        _report("streamed fp32 residual", x, x0 + pre, 2e-3)
+    elif kind == "gelu2":
+        out, outp = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
+        o.gemm_bf16(A, B, bias=bias, act=1, out_bf16=out, out_pre=outp, tile_config=4)
+        _report("streamed pre-activation", outp, pre, 1e-2)
+        _report("streamed activation", out, _ref_act(pre, 1, None), 1e-2)
+    else:
+        out = torch.empty(M, N, device="cuda", dtype=dt)
+        act = 1 if kind == "gelu" else 0
+        o.gemm_bf16(A, B, bias=bias, act=act, out_bf16=out, tile_config=4)
+        _report("streamed 16-bit out", out, _ref_act(pre, act, None), 1e-2)
+
+
+def test_gemm_streaming_config_refuses_what_it_does_not_cover():
+    from cclip_hip._lib import CclipError
+    o = _ops()
+    A = torch.zeros(300, 768, device="cuda", dtype=torch.bfloat16)       # M not a multiple of 256
+    B = torch.zeros(128, 768, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(CclipError):
+        o.gemm_bf16(A, B, out_bf16=torch.empty(300, 128, device="cuda", dtype=torch.bfloat16), tile_config=4)
+    A = torch.zeros(256, 256, device="cuda", dtype=torch.bfloat16)       # K too short for the streaming window
+    B = torch.zeros(128, 256, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(CclipError):
+        o.gemm_bf16(A, B, out_bf16=torch.empty(256, 128, device="cuda", dtype=torch.bfloat16), tile_config=4)
