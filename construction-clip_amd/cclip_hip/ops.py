@@ -316,6 +316,49 @@ def attention_decode(q, kcache, vcache, out, *, H: int, S: int, scale=None) -> N
         "cclip_attention_decode")
 
 
+class BlockPtrs(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_w", "ln2_b", "w_fc", "b_fc", "w_proj", "b_proj")]
+
+
+class DecodeDesc(ctypes.Structure):
+    _fields_ = [("n_layer", c_int), ("n_seq", c_int), ("width", c_int), ("heads", c_int), ("hidden", c_int), ("act", c_int),
+                ("linear_layout", c_int), ("pos", c_int),
+                ("blocks", ctypes.POINTER(BlockPtrs)), ("x", c_void_p), ("kcache", c_void_p), ("vcache", c_void_p),
+                ("ld_layer", c_long), ("ld_seq", c_long), ("scratch16", c_void_p),
+                ("lnf_w", c_void_p), ("lnf_b", c_void_p), ("wte16", c_void_p), ("vocab", c_int), ("logits", c_void_p), ("ld_logits", c_long)]
+
+
+def block_ptr_array(blocks):
+    """ctypes array of per-layer weight pointers for cclip_gpt2_decode_step (blocks: cclip_hip.stack.BlockWeights)."""
+    arr = (BlockPtrs * len(blocks))()
+    for i, w in enumerate(blocks):
+        for n, _ in BlockPtrs._fields_:
+            t = getattr(w, n)
+            setattr(arr[i], n, 0 if t is None else t.data_ptr())
+    return arr
+
+
+def gpt2_decode_step(blocks_arr, n_layer, x, kcache, vcache, pos, scratch16, *, heads, hidden, act, linear_layout,
+                     lnf_w=None, lnf_b=None, wte16=None, logits=None) -> None:
+    """One KV-cached decode step for x.shape[0] sequences, issued natively (cclip_gpt2_decode_step).
+    kcache / vcache: [n_layer, n_seq_alloc, max_len, width] 16-bit; x: fp32 [n_seq, width] (in place)."""
+    _req(x, torch.float32, "x")
+    nb, D = x.shape
+    assert x.is_contiguous() and kcache.dim() == 4 and kcache.stride(3) == 1 and kcache.stride(2) == D and kcache.stride() == vcache.stride()
+    assert scratch16.numel() >= nb * (5 * D + hidden) and scratch16.dtype == kcache.dtype
+    d = DecodeDesc()
+    d.n_layer, d.n_seq, d.width, d.heads, d.hidden, d.act, d.linear_layout, d.pos = n_layer, nb, D, heads, hidden, act, int(linear_layout), pos
+    d.blocks = blocks_arr
+    d.x, d.kcache, d.vcache = x.data_ptr(), kcache.data_ptr(), vcache.data_ptr()
+    d.ld_layer, d.ld_seq = kcache.stride(0), kcache.stride(1)
+    d.scratch16 = scratch16.data_ptr()
+    if logits is not None:
+        _req(logits, torch.float32, "logits")
+        d.lnf_w, d.lnf_b, d.wte16 = lnf_w.data_ptr(), lnf_b.data_ptr(), wte16.data_ptr()
+        d.vocab, d.logits, d.ld_logits = wte16.shape[0], logits.data_ptr(), logits.stride(0)
+    check(_fn("cclip_gpt2_decode_step", kcache)(ctypes.byref(d), _stream()), "cclip_gpt2_decode_step")
+
+
 # --------------------------------------------------------------------------------------------
 # exact fp32 GEMM:  C = alpha * A @ B^T-like contraction with arbitrary strides
 # --------------------------------------------------------------------------------------------

@@ -40,7 +40,7 @@ def generate_beam(model, tokenizer, beam_size: int = 3, prompt=None, embed=None,
         generated = model.gpt.transformer.wte(tokens)
     cache = None
     step_in = generated                                   # prefill: the whole prefix; afterwards one token per beam
-    for _ in range(entry_length):
+    for step in range(entry_length):
         logits, cache = _step_logits(model, step_in, cache)
         logits = logits / (temperature if temperature > 0 else 1.0)
         logits = logits.softmax(-1).log()
@@ -68,8 +68,11 @@ def generate_beam(model, tokenizer, beam_size: int = 3, prompt=None, embed=None,
             is_stopped = is_stopped[next_tokens_source]
         step_in = model.gpt.transformer.wte(next_tokens.squeeze(1)).view(beam_size, 1, -1)
         is_stopped = is_stopped + next_tokens.eq(stop_token).squeeze(1)
-        if is_stopped.all():
-            break
+        # `is_stopped.all()` is a device -> host sync; a stopped beam only ever appends token 0 at score 0 and keeps its length,
+        # so looking every 4th step (and on the last) returns the same texts, lengths and scores while the host runs ahead
+        if (step & 3) == 3 or step == entry_length - 1:
+            if is_stopped.all():
+                break
     scores = scores / seq_lengths
     order = scores.argsort(descending=True)
     output_list = tokens.cpu().numpy()

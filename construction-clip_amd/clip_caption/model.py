@@ -543,10 +543,25 @@ class ClipCaptionModel(nn.Module):
         if pos >= cache.max_len:
             raise RuntimeError(f"sequence longer than n_positions = {cache.max_len}")
         x = emb.view(B, D) + wpe[pos]
-        xo = self._stack.decode_step(x, cache.k, cache.v, pos)
+        if os.environ.get("CCLIP_DECODE_DRIVER", "native") != "native":       # launch by launch from Python (reference form)
+            xo = self._stack.decode_step(x, cache.k, cache.v, pos)
+            cache.length = pos + 1
+            rows = torch.arange(B, device=dev, dtype=torch.int32)
+            return self._lm_rows(xo, rows, False)[0].view(B, 1, -1), cache
+        # the whole per-token launch sequence (and ln_f + lm_head) from one native call
+        st = self._stack
+        if getattr(self, "_decode_ptrs", None) is None or self._decode_ptrs[0] is not self._arena:
+            self._decode_ptrs = (self._arena, ops.block_ptr_array(st.blocks))
+        V = g.vocab_size
+        p = self._arena.params
+        hidden = st.geo.hidden or 4 * D
+        scratch = torch.empty(B * (5 * D + hidden), device=dev, dtype=self.compute_dtype)
+        logits = torch.empty(B, (V + 7) // 8 * 8, device=dev, dtype=torch.float32)[:, :V]
+        ops.gpt2_decode_step(self._decode_ptrs[1], g.n_layer, x, cache.k, cache.v, pos, scratch, heads=st.geo.heads, hidden=hidden,
+                             act=st.geo.act, linear_layout=st.geo.linear_layout, lnf_w=p["model.transformer.ln_f.weight"].data,
+                             lnf_b=p["model.transformer.ln_f.bias"].data, wte16=self._arena.b["model.transformer.wte.weight"], logits=logits)
         cache.length = pos + 1
-        rows = torch.arange(B, device=dev, dtype=torch.int32)
-        return self._lm_rows(xo, rows, False)[0].view(B, 1, -1), cache
+        return logits.view(B, 1, -1) if logits.is_contiguous() else logits.unsqueeze(1), cache
 
     def _embed_and_run(self, tokens, prefix, attribute, mask, train: bool):
         self._ensure_runtime()

@@ -34,7 +34,7 @@ def _deps_mtime():
 
 
 # translation units that touch 16-bit operands are built twice: bf16 (default) and IEEE fp16 (-DCCLIP_F16)
-DUAL = ("gemm_bf16", "attention", "layernorm", "embed", "loss", "optim")   # "attention" also matches attention_small
+DUAL = ("gemm_bf16", "attention", "layernorm", "embed", "loss", "optim", "decode")   # "attention" also matches attention_small
 
 
 def _jobs():

@@ -35,6 +35,7 @@ bool cclip_gemm_launch_cfg1(int lay, int act, dim3 grid, hipStream_t stream, con
 bool cclip_gemm_launch_cfg2(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg3(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg4(int lay, int act, hipStream_t stream, const GemmArgs& a);
+bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmArgs& a);
 
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
@@ -98,6 +99,9 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
 #endif
 
   int cfg = d->tile_config;
+  // M <= 8 against K-strided weights (the projections of a KV-cached decode step): weight-read-bound GEMV path
+  if (cfg == 0 && splits == 1 && d->M <= 8 && cclip_gemm_launch_skinny(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a))
+    return cclip_launch_status();
   if (cfg == 4) {     // persistent streaming-epilogue kernel: forward layout, full tiles only - refused (not silently replaced) otherwise
     if (splits > 1 || !cclip_gemm_launch_cfg4(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
     return cclip_launch_status();

@@ -24,6 +24,10 @@ struct GemmArgs {
   float* out_f32; bf16* out_bf16; bf16* out_pre; long ldc;
   int act;
   float* split_ws;   // != nullptr: raw fp32 partial tile stores to split_ws[z][M][N]
+  // skinny (decode) path only, set by the native decode driver: A = LayerNorm(ln_x) computed in the kernel; columns
+  // [kv_width, 3*kv_width) of the output also go to the KV cache row of each sequence
+  const float* ln_x = nullptr; long ln_ldx = 0; const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
+  bf16* kv_k = nullptr; bf16* kv_v = nullptr; long kv_ld_seq = 0; int kv_width = 0;
 #ifdef CCLIP_GEMM_STAMPS
   unsigned long long* stamps;   // diagnostics build only: [tile][8] = hw id, t_start, t_issued, t_first, t_kdone, t_end (100 MHz)
 #endif

@@ -211,6 +211,31 @@ int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      hipStream_t stream);
 int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
+/* ---- native driver of one KV-cached GPT-2 decode step ------------------------------------------
+ * One call = the whole per-token launch sequence (per layer: ln_1, qkv GEMM, cache append, decode attention,
+ * out-proj GEMM + residual, ln_2, fc GEMM + activation, proj GEMM + residual; then optionally ln_f + tied lm_head)
+ * for n_seq sequences - the body of the reference's generate_beam / generate2 loops
+ * (CLIP_prefix_caption/test.py:381,468), which re-run `model.gpt(inputs_embeds=generated)` on the whole sequence.
+ * Issued from C++ so that a step costs ~100 kernel launches, not ~100 Python -> ctypes round trips.
+ * x: fp32 [n_seq, width], in = token embedding + position embedding of position `pos`, out = final hidden state.
+ * kcache / vcache: 16-bit, element (layer l, sequence b, position s, column c) at l*ld_layer + b*ld_seq + s*width + c;
+ * positions [0, pos) must be filled; position pos is written.  scratch16: n_seq * (5*width + hidden) 16-bit elements.
+ * linear_layout: 1 = nn.Linear [out,in] weights, 0 = GPT-2 Conv1D [in,out].  logits == NULL skips the head. */
+typedef struct cclip_block_ptrs {
+  const float* ln1_w; const float* ln1_b; const void* w_qkv; const float* b_qkv; const void* w_o; const float* b_o;
+  const float* ln2_w; const float* ln2_b; const void* w_fc; const float* b_fc; const void* w_proj; const float* b_proj;
+} cclip_block_ptrs;
+typedef struct cclip_decode_desc {
+  int32_t n_layer, n_seq, width, heads, hidden, act, linear_layout, pos;
+  const cclip_block_ptrs* blocks;
+  float* x;
+  void* kcache; void* vcache;
+  int64_t ld_layer, ld_seq;
+  void* scratch16;
+  const float* lnf_w; const float* lnf_b; const void* wte16; int32_t vocab; float* logits; int64_t ld_logits;
+} cclip_decode_desc;
+int cclip_gpt2_decode_step(const cclip_decode_desc* d, hipStream_t stream);
+
 /* ---- IEEE fp16 twins ---------------------------------------------------------------------------
  * Every entry point above whose 16-bit buffers are bf16 has a twin with the identical signature that
  * treats them as IEEE fp16 (same MFMA rate on gfx950; 3 more mantissa bits - the reference's own CUDA
@@ -237,6 +262,7 @@ int cclip_colsum_f16(const void* in, int32_t in_is_f16, int64_t ld, int32_t R, i
 int cclip_xent_rows_f16(const float* logits, int64_t ld, int32_t R, int32_t C, const int32_t* labels,
                         int32_t ignore_index, float grad_scale, float* loss_row, int32_t* pred,
                         void* dlogits, int32_t dlogits_is_f16, int64_t ldd, float* rowdot, hipStream_t stream);
+int cclip_gpt2_decode_step_f16(const cclip_decode_desc* d, hipStream_t stream);
 int cclip_adamw_step_f16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int32_t step,
                          int32_t correct_bias, float grad_scale, int32_t mode, void* f16_shadow,

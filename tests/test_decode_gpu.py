@@ -103,3 +103,28 @@ def test_generate2_matches_oracle_and_stops():
     assert torch.equal(tokens.cpu(), rt), (tokens.cpu(), rt)
     assert int(tokens[0, -1]) == 26 and tokens.shape[1] <= 12         # stopped on the stop token
     assert text == " ".join(str(int(t)) for t in rt[0])
+
+
+def test_native_decode_driver_equals_python_launch_sequence(monkeypatch):
+    """cclip_gpt2_decode_step (one native call per token; LayerNorm and the cache append fused into the skinny projections)
+    against BlockStack.decode_step (stand-alone kernels launched one by one from Python): same arithmetic up to the last
+    ulp of the LayerNorm statistics, so the 16-bit operands can differ in a rare rounding - compared at rounding level."""
+    geo, sd, model, prefix, attribute = _model(half=False)
+    g = torch.Generator().manual_seed(7)
+    emb = torch.randn(3, 7, geo.n_embd, generator=g) * 0.1
+    nxt = torch.randn(4, 3, 1, geo.n_embd, generator=g) * 0.1
+    outs = {}
+    for mode in ("python", "native"):
+        monkeypatch.setenv("CCLIP_DECODE_DRIVER", mode)
+        with torch.no_grad():
+            cache = model.gpt(inputs_embeds=emb.cuda(), use_cache=True).past_key_values
+            steps = []
+            for i in range(4):
+                o = model.gpt(inputs_embeds=nxt[i].cuda(), past_key_values=cache)
+                cache = o.past_key_values
+                steps.append(o.logits.clone())
+        outs[mode] = (steps, cache.k[:, :, :cache.length].clone(), cache.v[:, :, :cache.length].clone())
+    for a, b in zip(outs["python"][0], outs["native"][0]):
+        assert (a - b).abs().max() < 5e-3, (a - b).abs().max()
+    for i in (1, 2):
+        assert (outs["python"][i].float() - outs["native"][i].float()).abs().max() < 2e-2

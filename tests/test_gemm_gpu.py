@@ -208,3 +208,34 @@ def test_gemm_streaming_config_refuses_what_it_does_not_cover():
     B = torch.zeros(128, 256, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(CclipError):
         o.gemm_bf16(A, B, out_bf16=torch.empty(256, 128, device="cuda", dtype=torch.bfloat16), tile_config=4)
+
+
+# ---- skinny path: M <= 8 rows against K-strided (Conv1D) weights = the projections of a KV-cached decode step -----------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,kind", [(3, 2304, 768, "out16"), (1, 768, 768, "res"), (3, 3072, 768, "gelu_new"), (5, 768, 3072, "res"),
+                                         (8, 384, 128, "out16"), (2, 136, 200, "res"), (3, 384, 128, "pre")])
+def test_gemm_skinny_decode_shapes(M, N, K, kind, dt):
+    o = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(dt)
+    W = (torch.randn(K, N, device="cuda", generator=g) * 0.05).to(dt)          # Conv1D layout [in, out]
+    bias = torch.randn(N, device="cuda", generator=g)
+    pre = A.float() @ W.float() + bias
+    if kind == "res":
+        x0 = torch.randn(M, N, device="cuda", generator=g)
+        x = x0.clone()
+        o.gemm_bf16(A, W, b_kcontig=False, bias=bias, residual=x, out_f32=x)
+        _report("skinny residual", x, x0 + pre, 2e-3)
+        x1 = x0.clone()
+        o.gemm_bf16(A, W, b_kcontig=False, bias=bias, residual=x1, out_f32=x1, tile_config=1)       # the MFMA tile kernel on the same call
+        assert (x - x1).abs().max() <= 2e-3 * (x0 + pre).abs().max()
+    elif kind == "pre":
+        out, outp = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
+        o.gemm_bf16(A, W, b_kcontig=False, bias=bias, act=3, out_bf16=out, out_pre=outp)
+        _report("skinny pre", outp, pre, 1e-2)
+        _report("skinny act", out, _ref_act(pre, 3, None), 1e-2)
+    else:
+        act = 3 if kind == "gelu_new" else 0
+        out = torch.empty(M, N, device="cuda", dtype=dt)
+        o.gemm_bf16(A, W, b_kcontig=False, bias=bias, act=act, out_bf16=out)
+        _report("skinny 16-bit out", out, _ref_act(pre, act, None), 1e-2)
