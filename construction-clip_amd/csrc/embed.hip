@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int* __res
     int tok = text[r];
     tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
     const long src = (long)(r / L) * seq_stride + seq_off + (r % L);
+    // rows whose gradient is exactly zero add nothing: in the causal text tower that is every position after the EOT token
+    // (about half of a 77-token batch, all of them the same padding id 0 -> one hot row of contended atomics)
+    bool any = false;
+    for (int col = lane; col < D; col += 64) any |= dx[src * lddx + col] != 0.f;
+    if (__ballot(any) == 0) continue;
     for (int col = lane; col < D; col += 64) atomicAdd(demb + (long)tok * D + col, dx[src * lddx + col]);
   }
 }

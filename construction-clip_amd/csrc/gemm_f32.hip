@@ -33,22 +33,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool a_kfast = sak == 1, b_kfast = sbk == 1;
+  // register-staged prefetch: the global loads of K-tile k0+16 are in flight while tile k0 is multiplied
+  float ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      int m, k;
+      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
+      ra[i] = (bm0 + m < M && k0 + k < K) ? A[(long)(bm0 + m) * sam + (long)(k0 + k) * sak] : 0.f;
+      int n, kb;
+      if (b_kfast) { n = idx >> 4; kb = idx & 15; } else { kb = idx >> 6; n = idx & 63; }
+      rb[i] = (bn0 + n < N && k0 + kb < K) ? B[(long)(bn0 + n) * sbn + (long)(k0 + kb) * sbk] : 0.f;
+    }
+  };
+  gload(0);
   for (int k0 = 0; k0 < K; k0 += FBK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i;
       int m, k;
       if (a_kfast) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
-      float v = 0.f;
-      if (bm0 + m < M && k0 + k < K) v = A[(long)(bm0 + m) * sam + (long)(k0 + k) * sak];
-      As[m * FLD + k] = v;
+      As[m * FLD + k] = ra[i];
       int n, kb;
       if (b_kfast) { n = idx >> 4; kb = idx & 15; } else { kb = idx >> 6; n = idx & 63; }
-      float w = 0.f;
-      if (bn0 + n < N && k0 + kb < K) w = B[(long)(bn0 + n) * sbn + (long)(k0 + kb) * sbk];
-      Bs[n * FLD + kb] = w;
+      Bs[n * FLD + kb] = rb[i];
     }
     __syncthreads();
+    if (k0 + FBK < K) gload(k0 + FBK);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       float af[2], bf[2];
