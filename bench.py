@@ -236,7 +236,8 @@ def main():
     ap.add_argument("--mode", choices=["train", "fwd", "image", "caption"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="ViT-B/32")
-    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit MFMA operand type")
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default="bf16",
+                    help="MFMA operand type; fp8 = e4m3 qkv / fc projections of the image tower (inference modes only), bf16 elsewhere")
     ap.add_argument("--tower-streams", type=int, default=int(os.environ.get("CCLIP_TOWER_STREAMS", "2")),
                     help="2 = run the image and text towers (forward and backward) on two HIP streams")
     args = ap.parse_args()
@@ -256,12 +257,16 @@ def main():
     dev = torch.device("cuda", local)
     geo = MODELS[args.model]
     B = args.batch or (256 if args.mode == "caption" else 1024)
-    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    cdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    if args.dtype == "fp8" and args.mode not in ("image", "fwd"):
+        raise SystemExit("--dtype fp8 is an inference path: use --mode image or --mode fwd")
     if args.mode == "caption":
         return caption_main(args, rank, world, dev, B, cdt)
 
-    model = clip.build_model(init_state_dict(geo, 567), torch.bfloat16 if args.dtype == "bf16" else torch.float16).to(dev)
+    model = clip.build_model(init_state_dict(geo, 567), cdt).to(dev)
     model.train()
+    if args.dtype == "fp8":
+        model.eval().fp8_projections()
     parallel.broadcast_parameters(model)
     opt = coptim.AdamW(model, lr=1e-5)                       # CLIP/train.py:143 (HF AdamW, lr 1e-5)
     sched = coptim.get_linear_schedule_with_warmup(opt, 5000, 1000 * 50)   # CLIP/train.py:145-147

@@ -316,6 +316,45 @@ def attention_decode(q, kcache, vcache, out, *, H: int, S: int, scale=None) -> N
         "cclip_attention_decode")
 
 
+# --------------------------------------------------------------------------------------------
+# fp8 (e4m3) inference projections
+# --------------------------------------------------------------------------------------------
+def quantize_rows_fp8(x16: torch.Tensor, out8: torch.Tensor, scale: torch.Tensor) -> None:
+    """x16 [R, C] 16-bit -> out8 [R, C] uint8 (e4m3 bytes), scale [R] fp32 (x ~= scale[r] * fp8)."""
+    _req16(x16, "x16"); _req(scale, torch.float32, "scale")
+    assert out8.dtype == torch.uint8 and x16.dim() == 2 and out8.shape == x16.shape and x16.stride(1) == 1 and out8.stride(1) == 1
+    R, C = x16.shape
+    check(_fn("cclip_quantize_rows_fp8", x16)(_p(x16), c_long(x16.stride(0)), c_int(R), c_int(C), _p(out8), c_long(out8.stride(0)),
+                                             _p(scale), _stream()), "cclip_quantize_rows_fp8")
+
+
+def layernorm_fwd_fp8(x: torch.Tensor, gamma, beta, out8: torch.Tensor, scale: torch.Tensor, *, rows: int, eps: float = 1e-5) -> None:
+    _req(x, torch.float32, "x"); _req(scale, torch.float32, "scale")
+    assert out8.dtype == torch.uint8 and out8.stride(-1) == 1
+    check(lib.cclip_layernorm_fwd_fp8(_p(x), c_long(x.stride(-2)), c_int(rows), c_int(x.shape[-1]), _p(gamma), _p(beta), c_float(eps),
+                                      _p(out8), c_long(out8.stride(-2)), _p(scale), _stream()), "cclip_layernorm_fwd_fp8")
+
+
+def gemm_fp8(A8, scale_a, B8, scale_b, out16, *, bias=None, act: int = ACT_NONE, M: Optional[int] = None) -> None:
+    """out16[m][n] = act(scale_a[m] * scale_b[n] * sum_k A8[m][k] B8[n][k] + bias[n]); A8 [M,K], B8 [N,K] uint8 e4m3."""
+    assert A8.dtype == torch.uint8 and B8.dtype == torch.uint8 and A8.stride(1) == 1 and B8.stride(1) == 1
+    _req16(out16, "out16")
+    Mx, K = A8.shape
+    N = B8.shape[0]
+    M = Mx if M is None else M
+    assert B8.shape[1] == K and out16.shape[1] == N and out16.shape[0] >= M
+    ev = None
+    if GEMM_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    check(_fn("cclip_gemm_fp8", out16)(_p(A8), c_long(A8.stride(0)), _p(scale_a), _p(B8), c_long(B8.stride(0)), _p(scale_b), c_int(M),
+                                      c_int(N), c_int(K), _p(bias), c_int(act), _p(out16), c_long(out16.stride(0)), _stream()),
+          "cclip_gemm_fp8")
+    if ev is not None:
+        ev[1].record()
+        GEMM_EVENTS.append((ev[0], ev[1], 2.0 * M * N * K, (1, 1), (M, N, K)))
+
+
 class BlockPtrs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_w", "ln2_b", "w_fc", "b_fc", "w_proj", "b_proj")]
 

@@ -93,6 +93,25 @@ class BlockStack:
     def __init__(self, geo: StackGeometry, blocks: List[BlockWeights], scratch: Scratch,
                  dtype: torch.dtype = torch.bfloat16):
         self.geo, self.blocks, self.scratch, self.dtype = geo, blocks, scratch, dtype
+        # fp8 (e4m3) inference projections (BASELINE config 5): the LN-fed GEMMs (qkv, fc) take their A operand as e4m3
+        # rows straight from a LayerNorm with fused quantisation, weights quantised per output channel once
+        self.fp8 = False
+        self._fp8_weights = None
+
+    def quantise_weights_fp8(self) -> None:
+        """(Re)build the e4m3 copies + per-channel scales of every block's qkv / fc weights from the 16-bit shadows."""
+        assert self.geo.linear_layout, "fp8 projections: nn.Linear weight layout only"
+        out = []
+        for w in self.blocks:
+            ent = {}
+            for name in ("w_qkv", "w_fc"):
+                m = getattr(w, name)
+                q = torch.empty(m.shape, device=m.device, dtype=torch.uint8)
+                sc = torch.empty(m.shape[0], device=m.device, dtype=torch.float32)
+                ops.quantize_rows_fp8(m, q, sc)
+                ent[name] = (q, sc)
+            out.append(ent)
+        self._fp8_weights = out
 
     # ------------------------------------------------------------------ forward
     def alloc_saved(self, B: int, device, T: Optional[int] = None) -> dict:
@@ -144,8 +163,19 @@ class BlockStack:
                 xn2, h = xn1, None
                 x_in = x_mid = x_out = x
                 m1 = r1 = m2 = r2 = lse_l = None
-            ops.layernorm_fwd(x_in, w.ln1_w, w.ln1_b, rows=M, out_bf16=xn1, mean=m1, rstd=r1)
-            ops.gemm_bf16(xn1, w.w_qkv, b_kcontig=kc, bias=w.b_qkv, out_bf16=qkv, M=M)
+            f8 = self.fp8 and not train and kc and D % 16 == 0
+            if f8:
+                if self._fp8_weights is None:
+                    self.quantise_weights_fp8()
+                if l == 0:
+                    x8 = torch.empty(M, D, device=dev, dtype=torch.uint8)
+                    sx = torch.empty(M, device=dev, dtype=torch.float32)
+                wq8, swq = self._fp8_weights[l]["w_qkv"]
+                ops.layernorm_fwd_fp8(x_in, w.ln1_w, w.ln1_b, x8, sx, rows=M)
+                ops.gemm_fp8(x8, sx, wq8, swq, qkv, bias=w.b_qkv, M=M)
+            else:
+                ops.layernorm_fwd(x_in, w.ln1_w, w.ln1_b, rows=M, out_bf16=xn1, mean=m1, rstd=r1)
+                ops.gemm_bf16(xn1, w.w_qkv, b_kcontig=kc, bias=w.b_qkv, out_bf16=qkv, M=M)
             if kv_out is not None:       # data movement only
                 kv_out[0][l, :B, :T].copy_(qkv[:M, D:2 * D].view(B, T, D))
                 kv_out[1][l, :B, :T].copy_(qkv[:M, 2 * D:3 * D].view(B, T, D))
@@ -157,8 +187,13 @@ class BlockStack:
                 ops.attention_small_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H,
                                         head_dim=geo.head_dim, lse=lse_l)
             ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in, out_f32=x_mid, M=M)
-            ops.layernorm_fwd(x_mid, w.ln2_w, w.ln2_b, rows=M, out_bf16=xn2, mean=m2, rstd=r2)
-            ops.gemm_bf16(xn2, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, out_pre=h, M=M)
+            if f8 and geo.act in (ops.ACT_NONE, ops.ACT_QUICKGELU):
+                wf8, swf = self._fp8_weights[l]["w_fc"]
+                ops.layernorm_fwd_fp8(x_mid, w.ln2_w, w.ln2_b, x8, sx, rows=M)
+                ops.gemm_fp8(x8, sx, wf8, swf, g, bias=w.b_fc, act=geo.act, M=M)
+            else:
+                ops.layernorm_fwd(x_mid, w.ln2_w, w.ln2_b, rows=M, out_bf16=xn2, mean=m2, rstd=r2)
+                ops.gemm_bf16(xn2, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, out_pre=h, M=M)
             ops.gemm_bf16(g, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=x_mid, out_f32=x_out, M=M)
             x = x_out
         return x

@@ -202,6 +202,21 @@ class CLIP(nn.Module):
             vis_names=[n for n in ar.names if n.startswith("visual.")],
             txt_names=[n for n in ar.names if not n.startswith("visual.") and n != "logit_scale"],
         )
+        self._rt["vis"].fp8, self._rt["txt"].fp8 = getattr(self, "_fp8_projections", (False, False))
+
+    def fp8_projections(self, enabled: bool = True, text: bool = False):
+        """INFERENCE ONLY: run the LayerNorm-fed projections (qkv, fc) of the image tower - and, with text=True, of the text
+        tower - with e4m3 operands on the block-scaled fp8 MFMA (per-token / per-output-channel scales; BASELINE.json
+        configs[4] is encode_image).  Weights are re-quantised from the current 16-bit shadows at this call; call again after
+        changing parameters.  No reference fp8 behaviour exists: accuracy is bounded by test against the fp32 oracle (image
+        features ~2.5e-2 relative, cosine > 0.999; the 12-layer causal text tower is ~7e-2 and therefore opt-in), not matched."""
+        self._fp8_projections = (bool(enabled), bool(enabled and text))
+        if self._arena is not None and self._rt is not None:
+            self._arena.refresh_shadows()
+            for k, on in zip(("vis", "txt"), self._fp8_projections):
+                self._rt[k].fp8 = on
+                self._rt[k]._fp8_weights = None
+        return self
 
     def initialize_parameters(self, seed: int = 567, finetuned_like: bool = True):
         from .weights import init_state_dict

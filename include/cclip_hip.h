@@ -211,6 +211,24 @@ int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      hipStream_t stream);
 int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
+/* ---- fp8 (OCP e4m3) inference projections --------------------------------------------------------
+ * BASELINE.json configs[4] (ViT-L/14@336px encode_image, fp8 MFMA path).  No reference behaviour exists for fp8
+ * (the reference runs fp16 / fp32): parity of this path is unpinned and bounded against the fp32 oracle by test.
+ * cclip_quantize_rows_fp8: x16 [rows, cols] (cols % 8 == 0) -> e4m3 bytes [rows, cols] and scale[r] = amax_r / 448
+ *   (1 for an all-zero row), x ~= scale[r] * fp8.  Per token for activations, per output channel for weights.
+ * cclip_gemm_fp8: out16[m][n] = act(scale_a[m] * scale_b[n] * sum_k A8[m][k] * B8[n][k] + bias[n]); A8 [M,K], B8 [N,K]
+ *   K-contiguous e4m3, K % 16 == 0, leading dimensions % 16 == 0, 16-byte aligned; act NONE or QUICKGELU.
+ *   v_mfma_scale_f32_16x16x128_f8f6f4 (the form that runs at 2x the bf16 rate on gfx950), block scales fixed at 1. */
+int cclip_quantize_rows_fp8(const void* x_bf16, int64_t ldx, int32_t rows, int32_t cols, void* out_fp8, int64_t ldo,
+                            float* scale, hipStream_t stream);
+/* LayerNorm (as cclip_layernorm_fwd) whose output is written as e4m3 rows + per-row scale: the A operand of the LN-fed
+ * projections (qkv, fc) with no separate quantisation pass. */
+int cclip_layernorm_fwd_fp8(const float* x, int64_t ldx, int32_t rows, int32_t D, const float* gamma, const float* beta,
+                            float eps, void* out_fp8, int64_t ldo, float* scale, hipStream_t stream);
+int cclip_gemm_fp8(const void* A8, int64_t lda, const float* scale_a, const void* B8, int64_t ldb, const float* scale_b,
+                   int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, void* out_bf16, int64_t ldc,
+                   hipStream_t stream);
+
 /* ---- native driver of one KV-cached GPT-2 decode step ------------------------------------------
  * One call = the whole per-token launch sequence (per layer: ln_1, qkv GEMM, cache append, decode attention,
  * out-proj GEMM + residual, ln_2, fc GEMM + activation, proj GEMM + residual; then optionally ln_f + tied lm_head)
@@ -263,6 +281,11 @@ int cclip_xent_rows_f16(const float* logits, int64_t ld, int32_t R, int32_t C, c
                         int32_t ignore_index, float grad_scale, float* loss_row, int32_t* pred,
                         void* dlogits, int32_t dlogits_is_f16, int64_t ldd, float* rowdot, hipStream_t stream);
 int cclip_gpt2_decode_step_f16(const cclip_decode_desc* d, hipStream_t stream);
+int cclip_quantize_rows_fp8_f16(const void* x_f16, int64_t ldx, int32_t rows, int32_t cols, void* out_fp8, int64_t ldo,
+                                float* scale, hipStream_t stream);
+int cclip_gemm_fp8_f16(const void* A8, int64_t lda, const float* scale_a, const void* B8, int64_t ldb, const float* scale_b,
+                       int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, void* out_f16, int64_t ldc,
+                       hipStream_t stream);
 int cclip_adamw_step_f16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int32_t step,
                          int32_t correct_bias, float grad_scale, int32_t mode, void* f16_shadow,
