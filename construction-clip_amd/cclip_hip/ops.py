@@ -317,6 +317,26 @@ def attention_decode(q, kcache, vcache, out, *, H: int, S: int, scale=None) -> N
 
 
 # --------------------------------------------------------------------------------------------
+# device-side preprocess (PIL's 8-bit bicubic resampler + crop + normalise)
+# --------------------------------------------------------------------------------------------
+def resample_h_u8(src_rows: torch.Tensor, bounds: torch.Tensor, kk: torch.Tensor, ksize: int, out: torch.Tensor) -> None:
+    """src_rows uint8 [rows, W, 3] -> out uint8 [rows, n, 3]; bounds int32 [n, 2], kk int32 [n, ksize]."""
+    assert src_rows.dtype == torch.uint8 and out.dtype == torch.uint8 and src_rows.is_cuda and src_rows.stride(2) == 1 and src_rows.stride(1) == 3
+    assert bounds.dtype == torch.int32 and kk.dtype == torch.int32 and bounds.is_contiguous() and kk.is_contiguous() and out.is_contiguous()
+    check(lib.cclip_resample_h_u8(_p(src_rows), c_long(src_rows.stride(0)), c_int(src_rows.shape[0]), _p(bounds), _p(kk), c_int(ksize),
+                                  c_int(out.shape[1]), _p(out), c_long(out.stride(0)), _stream()), "cclip_resample_h_u8")
+
+
+def resample_v_norm(tmp: torch.Tensor, row0: int, bounds: torch.Tensor, kk: torch.Tensor, ksize: int, mean, std, out: torch.Tensor) -> None:
+    """tmp uint8 [rows, n, 3] (input rows row0..) -> out fp32 [3, n, n] = ((u8 / 255) - mean) / std."""
+    _req(out, torch.float32, "out")
+    assert tmp.dtype == torch.uint8 and tmp.is_contiguous() and out.is_contiguous()
+    m3, s3 = (c_float * 3)(*mean), (c_float * 3)(*std)
+    check(lib.cclip_resample_v_norm(_p(tmp), c_long(tmp.stride(0)), c_int(row0), _p(bounds), _p(kk), c_int(ksize), c_int(out.shape[1]),
+                                    m3, s3, _p(out), _stream()), "cclip_resample_v_norm")
+
+
+# --------------------------------------------------------------------------------------------
 # fp8 (e4m3) inference projections
 # --------------------------------------------------------------------------------------------
 def quantize_rows_fp8(x16: torch.Tensor, out8: torch.Tensor, scale: torch.Tensor) -> None:

@@ -5,3 +5,4 @@ from . import simple_tokenizer  # noqa: F401  (attention.py:114 uses clip.simple
 from .model import CLIP, build_model  # noqa: F401
 from .loss import contrastive_loss, ContrastiveLoss  # noqa: F401
 from .graphs import GraphedCallable, graphed_encoders  # noqa: F401
+from .preprocess_device import DevicePreprocess  # noqa: F401

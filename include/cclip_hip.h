@@ -211,6 +211,18 @@ int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      hipStream_t stream);
 int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
+/* ---- device-side preprocess --------------------------------------------------------------------
+ * openai/CLIP's _transform(n) = Resize(n, BICUBIC) -> CenterCrop(n) -> ToTensor -> Normalize on a decoded 8-bit RGB image
+ * (HWC, 3 bytes per pixel), bit-identical to the PIL + numpy pipeline the reference runs in DataLoader workers
+ * (CLIP/train.py:56).  Two launches per image: a horizontal 8-bit resampling pass (PIL's integer resampler: windows and
+ * 2^22-scaled integer coefficients per output sample, computed on the host) over the rows the vertical pass needs and the
+ * columns that survive the crop, then the vertical pass fused with crop + (u8/255 - mean)/std -> fp32 [3, n, n].
+ * mean3 / std3 are HOST pointers to 3 floats. */
+int cclip_resample_h_u8(const uint8_t* in, int64_t in_ld, int32_t rows, const int32_t* bounds, const int32_t* kk,
+                        int32_t ksize, int32_t out_w, uint8_t* out, int64_t out_ld, hipStream_t stream);
+int cclip_resample_v_norm(const uint8_t* tmp, int64_t tmp_ld, int32_t row0, const int32_t* bounds, const int32_t* kk,
+                          int32_t ksize, int32_t n, const float* mean3, const float* std3, float* out, hipStream_t stream);
+
 /* ---- fp8 (OCP e4m3) inference projections --------------------------------------------------------
  * BASELINE.json configs[4] (ViT-L/14@336px encode_image, fp8 MFMA path).  No reference behaviour exists for fp8
  * (the reference runs fp16 / fp32): parity of this path is unpinned and bounded against the fp32 oracle by test.
