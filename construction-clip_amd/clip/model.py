@@ -309,30 +309,37 @@ class CLIP(nn.Module):
         dev = text.device
         if text.dim() != 2 or text.shape[1] != geo.context_length:
             raise RuntimeError(f"encode_text: expected [N,{geo.context_length}] token ids, got {tuple(text.shape)}")
-        B, L, D = text.shape[0], geo.context_length, geo.transformer_width
+        B, D = text.shape[0], geo.transformer_width
+        eot = text.detach().argmax(dim=-1)
+        # The tower is causal and only the EOT row is pooled: positions after the LAST EOT of the batch influence nothing.
+        # trim_text_padding runs the tower on [0, max EOT] only (real captions are ~10-30 tokens of the 77): identical
+        # features, fewer rows.  Off by default: it costs one device->host sync per call to learn the length.
+        L = geo.context_length
+        if getattr(self, "trim_text_padding", False):
+            L = max(2, int(eot.max().item()) + 1)
         M = B * L
-        tok = text.detach().to(torch.int32).contiguous()
+        tok = text.detach()[:, :L].to(torch.int32).contiguous()
         p = ar.params
-        saved = st.alloc_saved(B, dev) if train else None
+        saved = st.alloc_saved(B, dev, T=L) if train else None
         x = saved["xs"][0, 0] if train else torch.empty(M, D, device=dev, dtype=torch.float32)
         ops.text_embed(tok.view(-1), p["token_embedding.weight"].data, p["positional_embedding"].data, x, rows=M, L=L)
-        xo = st.forward(x, B, saved=saved)
+        xo = st.forward(x, B, saved=saved, T=L)
         # EOT = largest id in the row (openai/CLIP: x[arange, text.argmax(-1)]); integer index math only
-        rows = (torch.arange(B, device=dev) * L + text.detach().argmax(dim=-1)).to(torch.int32).contiguous()
+        rows = (torch.arange(B, device=dev) * L + eot).to(torch.int32).contiguous()
         pooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         stp = torch.empty(2, B, device=dev, dtype=torch.float32)
         ops.layernorm_fwd(xo, p["ln_final.weight"].data, p["ln_final.bias"].data, rows=B, row_index=rows, out_f32=pooled,
                           mean=stp[0], rstd=stp[1])
         feat = torch.empty(B, geo.embed_dim, device=dev, dtype=torch.float32)
         ops.gemm_f32(pooled, p["text_projection"].data.t(), feat)
-        ctx = dict(saved=saved, tok=tok, xo=xo, rows=rows, pooled=pooled, stp=stp, B=B) if train else None
+        ctx = dict(saved=saved, tok=tok, xo=xo, rows=rows, pooled=pooled, stp=stp, B=B, L=L) if train else None
         return feat, ctx
 
     def _text_backward(self, c: dict, dfeat: torch.Tensor):
         ar, geo, st = self._arena, self.geo, self._rt["txt"]
         p, g = ar.params, ar.g
         acc = ar.begin_backward()
-        B, L, D = c["B"], geo.context_length, geo.transformer_width
+        B, L, D = c["B"], c["L"], geo.transformer_width
         M = B * L
         dev = dfeat.device
         dfeat = dfeat.contiguous().float()
@@ -351,7 +358,10 @@ class CLIP(nn.Module):
                           dbeta=g["ln_final.bias"], accumulate=A("ln_final.weight"),
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
         dxb = st.backward(dx, dxb, c["saved"], acc)
-        ops.colsum(dx, g["positional_embedding"], sc.floats(ops.colsum_ws_floats(B, L * D)), R=B, C=L * D, ld=L * D,
+        gpos = g["positional_embedding"]
+        if L < geo.context_length and not A("positional_embedding"):
+            gpos[L:].zero_()                      # trimmed positions received no gradient
+        ops.colsum(dx, gpos.view(-1)[:L * D], sc.floats(ops.colsum_ws_floats(B, L * D)), R=B, C=L * D, ld=L * D,
                    accumulate=A("positional_embedding"))
         if not A("token_embedding.weight"):
             g["token_embedding.weight"].zero_()

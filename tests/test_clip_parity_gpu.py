@@ -265,3 +265,34 @@ def test_batched_zero_shot_and_embedding_extraction_match_per_image_calls():
     z = ZeroShotClassifier(model, prompts9, VIOLATION_TYPES)
     sim, idx, labels = z(img)
     assert torch.equal(idx[:1].cpu(), g["zs9_idx"]) and (sim[:1].cpu() - g["zs9_sim"]).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_trim_text_padding_changes_nothing_but_the_row_count(dtype):
+    """model.trim_text_padding runs the causal text tower on [0, last EOT of the batch] only: features, loss and gradients as
+    with all 77 positions (different tile shapes -> summation-order noise only)."""
+    import clip
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    geo = MODELS["test-small"]
+    img = synthetic_images(6, geo, 1).cuda()
+    txt = synthetic_text(6, geo, 2)
+    txt[:, 9:] = 0                                           # short captions: EOT somewhere in [1, 8]
+    for b in range(6):
+        txt[b, 1 + b] = geo.vocab_size - 1
+        txt[b, 2 + b:] = 0
+    txt = txt.cuda()
+    outs = []
+    for trim in (False, True):
+        model = clip.build_model(init_state_dict(geo, 7), dtype).cuda().train()
+        model.trim_text_padding = trim
+        li, lt = model(img, txt)
+        lab = torch.arange(6, device="cuda")
+        loss = (torch.nn.functional.cross_entropy(li, lab) + torch.nn.functional.cross_entropy(lt, lab)) / 2
+        loss.backward()
+        outs.append((li.detach(), loss.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert (outs[0][0] - outs[1][0]).abs().max() < 2e-3
+    assert abs(outs[0][1].item() - outs[1][1].item()) < 1e-4
+    assert set(outs[0][2]) == set(outs[1][2])
+    for n in outs[0][2]:
+        assert rel(outs[1][2][n], outs[0][2][n]) < 2e-2, n
+    assert torch.equal(outs[1][2]["positional_embedding"][8:], torch.zeros_like(outs[1][2]["positional_embedding"][8:]))
