@@ -1,6 +1,6 @@
 """Headline benchmark: image-text pairs/sec of the CLIP ViT-B/32 contrastive step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--mode train|fwd|image|caption] [--batch 1024]
+    python bench.py --gpus N --steps K --warmup W [--mode train|fwd|image|caption] [--batch 1024] [--dtype bf16|fp16|fp8]
 
 Workload (BASELINE.json configs[1]): CLIP/train.py's step `model(image, text)` -> symmetric CE ->
 backward -> AdamW, scaled to bs = 1024 pairs per GPU, synthetic 224x224 N(0,1) images + 77-token captions
@@ -14,7 +14,8 @@ N > 1: one process per GPU (torchrun contract), weak scaling (per-GPU batch fixe
 all-gather + reduce-scatter and SUM all-reduce of the flat gradient arena over RCCL.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     - dominant kernel family gemm_bf16_128<*> (97 % of the step's FLOPs): algorithmic FLOPs of
+  roofline     - dominant kernel family cclip_gemm_bf16 = gemm_bf16_kernel<*> / gemm_stream_kernel<*> (97 % of the step's
+                 FLOPs, ~78 % of its time): algorithmic FLOPs of
                  every launch in the timed region (2*M*N*K) / their summed durations (HIP events on the launch
                  stream), against the 2.5 PFLOP/s dense bf16 MFMA peak.
   cpu_baseline - the CPU oracle (kind "port": the reference's `clip` package is absent) timed
