@@ -277,102 +277,157 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Forward for sequences longer than 128 (ViT-B/16: 197, ViT-L/14: 257, ViT-L/14@336px: 577 tokens): same S^T = K Q^T /
 // O^T = V^T P^T formulation, tiled over 64-key blocks with the online-softmax recurrence.  One workgroup per
-// (batch, head, 64-query block); wave w owns queries 16w..16w+15 of the block; a K block and a V block (8 KiB each)
-// are staged per step.  Causal workgroups stop at their own diagonal block.
+// (batch, head, 128-query block); wave w owns the two 16-query tiles 32w.. of the block (every K / V fragment read from
+// LDS feeds two MFMAs); K / V blocks are double-buffered in LDS and the next block's global loads are in flight (in
+// registers) while the current block is multiplied - one barrier per block.  Causal workgroups stop at their diagonal.
+#define ALQ 2                                             // query tiles per wave
 __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const AttnArgs a, int nqb) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
-  char* Ks = smem;
-  char* Vs = smem + 64 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];          // [buffer][K | V][64 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb;
   const int b = bh / a.H, h = bh % a.H;
   const int T = a.T;
   const long row0 = (long)b * T;
-  const int qi = 64 * qb + 16 * wave + li;
-  const int qrow = qi < T ? qi : T - 1;
-  const bf16* qp = a.q + (row0 + qrow) * a.ldq + h * 64 + 8 * g;
-  const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
   const float NEG = -__builtin_inff();
-  float m = NEG, l = 0.f;
-  f32x4 o[4];
+  int qi[ALQ];
+  bf16x8 qf0[ALQ], qf1[ALQ];
+  float m[ALQ], l[ALQ];
+  f32x4 o[ALQ][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < ALQ; ++t) {
+    qi[t] = 128 * qb + 32 * wave + 16 * t + li;
+    const int qrow = qi[t] < T ? qi[t] : T - 1;
+    const bf16* qp = a.q + (row0 + qrow) * a.ldq + h * 64 + 8 * g;
+    qf0[t] = *(const bf16x8*)qp; qf1[t] = *(const bf16x8*)(qp + 32);
+    m[t] = NEG; l[t] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   int nkb = (T + 63) >> 6;
-  if (a.causal && qb + 1 < nkb) nkb = qb + 1;
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();                                   // every wave is done with the previous blocks
-    for (int idx = tid; idx < 64 * 8; idx += 256) {
-      const int row = idx >> 3, c = idx & 7, key = 64 * kb + row;
-      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+  if (a.causal) { const int last = (128 * qb + 127) >> 6; if (last + 1 < nkb) nkb = last + 1; }
+  // this thread's share of a block: rows r0, r0 + 32 of K and of V, 16-byte chunk c
+  const int r0 = tid >> 3, c = tid & 7;
+  uint4 pk[2], pv[2];
+  auto gload = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = 64 * kb + r0 + 32 * i;
+      pk[i] = make_uint4(0, 0, 0, 0); pv[i] = make_uint4(0, 0, 0, 0);
       if (key < T) {
-        kv = *(const uint4*)(a.k + (row0 + key) * a.ldk + h * 64 + c * 8);
-        vv = *(const uint4*)(a.v + (row0 + key) * a.ldv + h * 64 + c * 8);
+        pk[i] = *(const uint4*)(a.k + (row0 + key) * a.ldk + h * 64 + c * 8);
+        pv[i] = *(const uint4*)(a.v + (row0 + key) * a.ldv + h * 64 + c * 8);
       }
-      *(uint4*)(Ks + at_off(row, c)) = kv;
-      *(uint4*)(Vs + at_off(row, c)) = vv;
     }
-    __syncthreads();
-    f32x4 s[4];
+  };
+  auto lstore = [&](int buf) {
+    char* Ks = smem + buf * (2 * 64 * 128);
+    char* Vs = Ks + 64 * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *(uint4*)(Ks + at_off(r0 + 32 * i, c)) = pk[i];
+      *(uint4*)(Vs + at_off(r0 + 32 * i, c)) = pv[i];
+    }
+  };
+  gload(0);
+  lstore(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();                                   // block kb is in buffer kb & 1; everyone is done with buffer (kb+1) & 1
+    if (kb + 1 < nkb) gload(kb + 1);                   // in flight during this block's MFMAs
+    const char* Ks = smem + (kb & 1) * (2 * 64 * 128);
+    const char* Vs = Ks + 64 * 128;
+    f32x4 s[ALQ][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      s[kt] = CCLIP_MFMA_16x16x32(frag_row(Ks, 16 * kt + li, g), qf0, s[kt]);
-      s[kt] = CCLIP_MFMA_16x16x32(frag_row(Ks, 16 * kt + li, 4 + g), qf1, s[kt]);
+      const bf16x8 k0 = frag_row(Ks, 16 * kt + li, g), k1 = frag_row(Ks, 16 * kt + li, 4 + g);
+#pragma unroll
+      for (int t = 0; t < ALQ; ++t) {
+        s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s[t][kt] = CCLIP_MFMA_16x16x32(k0, qf0[t], s[t][kt]);
+        s[t][kt] = CCLIP_MFMA_16x16x32(k1, qf1[t], s[t][kt]);
+      }
     }
-    float bm = NEG;
+    // The softmax arithmetic, not the MFMAs, bounds this kernel at head_dim 64 (~10 VALU slots per score against 0.5 MFMA
+    // slots): scores go to the log2 domain with ONE multiply (scale * log2 e), exponentials are bare v_exp_f32, and blocks
+    // that need no masking (all but the last key block, no key padding, below the causal diagonal) skip the per-score tests.
+    const float sl2 = a.scale * 1.4426950408889634f;
+    const bool full = 64 * kb + 64 <= T && !a.keep && (!a.causal || 64 * kb + 63 <= 128 * qb + 32 * wave);
+    float alpha[ALQ];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int t = 0; t < ALQ; ++t) {
+      float bm = NEG;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 64 * kb + 16 * kt + 4 * g + r;
-        bool ok = key < T && (!a.causal || key <= qi);
-        if (ok && a.keep) ok = a.keep[row0 + key] != 0.f;
-        const float val = ok ? s[kt][r] * a.scale : NEG;
-        s[kt][r] = val;
-        bm = fmaxf(bm, val);
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s[t][kt][r] *= sl2;
+            bm = fmaxf(bm, s[t][kt][r]);
+          }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 64 * kb + 16 * kt + 4 * g + r;
+            bool ok = key < T && (!a.causal || key <= qi[t]);
+            if (ok && a.keep) ok = a.keep[row0 + key] != 0.f;
+            const float val = ok ? s[t][kt][r] * sl2 : NEG;
+            s[t][kt][r] = val;
+            bm = fmaxf(bm, val);
+          }
       }
-    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-    const float mn = fmaxf(m, bm);
-    const float msafe = mn == NEG ? 0.f : mn;
-    const float alpha = __expf(m - msafe);             // m = -inf (nothing seen yet) -> 0
-    float bl = 0.f;
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mn = fmaxf(m[t], bm);                 // running maximum, log2 domain
+      const float msafe = mn == NEG ? 0.f : mn;
+      alpha[t] = __builtin_amdgcn_exp2f(m[t] - msafe);  // m = -inf (nothing seen yet) -> 0
+      float bl = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = __expf(s[kt][r] - msafe);
-        s[kt][r] = pv;
-        bl += pv;
-      }
-    bl += __shfl_xor(bl, 16, 64);
-    bl += __shfl_xor(bl, 32, 64);
-    l = l * alpha + bl;
-    m = mn;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      bf16x8 pf;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { pf[j] = (bf16)s[2 * ss][j]; pf[4 + j] = (bf16)s[2 * ss + 1][j]; }
+        for (int r = 0; r < 4; ++r) {
+          const float pv_ = __builtin_amdgcn_exp2f(s[t][kt][r] - msafe);
+          s[t][kt][r] = pv_;
+          bl += pv_;
+        }
+      bl += __shfl_xor(bl, 16, 64);
+      bl += __shfl_xor(bl, 32, 64);
+      l[t] = l[t] * alpha[t] + bl;
+      m[t] = mn;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = CCLIP_MFMA_16x16x32(frag_tr(Vs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, o[dt]);
-    }
-  }
-  if (qi < T) {
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    bf16* op = a.o + (row0 + qi) * a.ldo + h * 64 + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
-      *(bf16x4*)(op + 16 * dt) = ov;
+        for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha[t];
     }
-    if (g == 0 && a.lse) a.lse[((long)b * a.H + h) * T + qi] = (m == NEG ? 0.f : m) + __logf(l);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      bf16x8 pf[ALQ];
+#pragma unroll
+      for (int t = 0; t < ALQ; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pf[t][j] = (bf16)s[t][2 * ss][j]; pf[t][4 + j] = (bf16)s[t][2 * ss + 1][j]; }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vf = frag_tr(Vs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane);
+#pragma unroll
+        for (int t = 0; t < ALQ; ++t) o[t][dt] = CCLIP_MFMA_16x16x32(vf, pf[t], o[t][dt]);
+      }
+    }
+    if (kb + 1 < nkb) lstore((kb + 1) & 1);            // its readers (block kb-1) all passed this iteration's barrier
+  }
+#pragma unroll
+  for (int t = 0; t < ALQ; ++t) {
+    if (qi[t] < T) {
+      const float inv = l[t] > 0.f ? 1.0f / l[t] : 0.f;
+      bf16* op = a.o + (row0 + qi[t]) * a.ldo + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov = {(bf16)(o[t][dt][0] * inv), (bf16)(o[t][dt][1] * inv), (bf16)(o[t][dt][2] * inv), (bf16)(o[t][dt][3] * inv)};
+        *(bf16x4*)(op + 16 * dt) = ov;
+      }
+      if (g == 0 && a.lse) a.lse[((long)b * a.H + h) * T + qi[t]] = (m[t] == NEG ? 0.f : m[t] * 0.6931471805599453f) + __logf(l[t]);
+    }
   }
 }
 
@@ -410,7 +465,7 @@ extern "C" int CCLIP_FN(cclip_attention_fwd)(const cclip_attn_desc* d, hipStream
   dim3 grid(d->B * d->H), block(256);
   const int nkt = (d->T + 15) / 16;
   if (d->T > 128) {
-    const int nqb = (d->T + 63) / 64;
+    const int nqb = (d->T + 127) / 128;
     hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(d->B * d->H * nqb), block, 0, stream, a, nqb);
     return cclip_launch_status();
   }
