@@ -76,7 +76,12 @@ typedef struct cclip_gemm_desc {
   int64_t ldc;
   int32_t split_k;
   float* split_ws;
-  int32_t tile_config; /* 0 = auto; 1 = 128x128 tile, 2 LDS stages; 2 = 256x128 tile, 3 stages (tuning / tests) */
+  int32_t tile_config; /* 0 = auto (128x128; M <= 8 rows against K-strided weights takes the skinny GEMV path);
+                        * 1 = 128x128 tile, 2 LDS stages; 2 = 256x128, 3 stages; 3 = 256x256, 2 stages;
+                        * 4 = persistent 256x128 with the epilogue streamed under the next tile's K loop - forward layout,
+                        *     M % 256 == 0, N % 128 == 0, N <= 4096, K >= 512 (640 with a residual), one of the three
+                        *     epilogue forms {16-bit out | pre-activation + activation | fp32 out + residual}; status 1 otherwise.
+                        * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
 } cclip_gemm_desc;
 int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream);
 
