@@ -233,9 +233,6 @@ class CLIP(nn.Module):
         if tuple(image.shape[1:]) != (3, geo.image_resolution, geo.image_resolution):
             raise RuntimeError(f"encode_image: expected [N,3,{geo.image_resolution},{geo.image_resolution}], got {tuple(image.shape)}")
         M = B * T
-        if train and T > 128:
-            raise NotImplementedError(f"{T}-token image tower: the attention backward kernel covers T <= 128 (ViT-B/32); "
-                                      "longer sequences are forward-only (encode_image) in this build")
         img = image.detach().to(torch.float32).contiguous()
         KP = 3 * P * P
         KPAD = (KP + 7) // 8 * 8                   # P = 14: 588 -> 592, rows stay 16-byte aligned for the GEMM's DMA
@@ -298,7 +295,16 @@ class CLIP(nn.Module):
                    ld=T * D, accumulate=A("visual.positional_embedding"))
         ops.colsum(dx, g["visual.class_embedding"], sc.floats(ops.colsum_ws_floats(B, D)), R=B, C=D, ld=T * D,
                    accumulate=A("visual.class_embedding"))
-        st._wgrad(dxb, c["patches"], g["visual.conv1.weight"].view(D, -1), M, A("visual.conv1.weight"))
+        gw = g["visual.conv1.weight"].view(D, -1)
+        if c["patches"].shape[1] == gw.shape[1]:
+            st._wgrad(dxb, c["patches"], gw, M, A("visual.conv1.weight"))
+        else:                                      # patch 14: im2col rows are zero-padded 588 -> 592; the pad columns' gradient is dropped
+            gpad = torch.empty(D, c["patches"].shape[1], device=dev, dtype=torch.float32)
+            st._wgrad(dxb, c["patches"], gpad, M, False)
+            if A("visual.conv1.weight"):
+                gw.add_(gpad[:, :gw.shape[1]])
+            else:
+                gw.copy_(gpad[:, :gw.shape[1]])
         ar.publish_grads(self._rt["vis_names"])
 
     # -- text tower -----------------------------------------------------------------------------

@@ -1,5 +1,5 @@
-// Fused multi-head attention (dh = 64) for gfx950: forward for any T (single-pass for T <= 128, key-block-tiled online
-// softmax beyond), backward for T <= 128.
+// Fused multi-head attention (dh = 64) for gfx950, forward and backward: one workgroup per (batch, head) for T <= 128,
+// key-block-tiled online softmax forward and a two-kernel (dK/dV by key block, dQ by query block) backward beyond.
 //
 // Replaces the scaled-dot-product core of nn.MultiheadAttention inside the `clip` package's
 // ResidualAttentionBlock (image tower: T=50 no mask; text tower: T=77 additive causal mask),
@@ -431,12 +431,199 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const AttnArgs a, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward for sequences longer than 128: the single-workgroup kernel above, cut along the key axis (dK, dV) and along
+// the query axis (dQ).  Both recompute S and dP from the saved log-sum-exp, as the short kernel does; delta = rowsum(dO*O)
+// is recomputed per staged query block.  Same operand roles as attn_bwd_kernel: query on accumulator rows, so P and dS
+// are B operands of dV^T = dO^T P and dK^T = Q^T dS without data movement; dS crosses LDS once for dQ^T = K^T dS^T.
+//
+// stage 64 rows [r0, r0+64) of a [T][64] head slice (zero rows >= T) - one 16-byte chunk per thread per 32 rows
+__device__ __forceinline__ void stage_block64(const bf16* g, long ld, long row0, int r0, int T, char* img, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 3) + 32 * i, c = tid & 7;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (r0 + row < T) val = *(const uint4*)(g + (row0 + r0 + row) * ld + c * 8);
+    *(uint4*)(img + at_off(row, c)) = val;
+  }
+}
+
+// lse and delta = rowsum(dO * O) of query rows [q0, q0 + 64) into LDS (rows >= T: lse = +big so that P = 0)
+__device__ __forceinline__ void stage_lse_delta64(const AttnArgs& a, long row0, int b, int h, int q0, float* lse_s, float* del_s, int tid) {
+  const int rr = tid >> 2, part = tid & 3, q = q0 + rr;
+  float acc = 0.f;
+  if (q < a.T) {
+    const bf16* op = a.o + (row0 + q) * a.ldo + h * 64 + part * 16;
+    const bf16* dp = a.dout + (row0 + q) * a.lddo + h * 64 + part * 16;
+    const bf16x8 o0 = *(const bf16x8*)op, o1 = *(const bf16x8*)(op + 8);
+    const bf16x8 d0 = *(const bf16x8*)dp, d1 = *(const bf16x8*)(dp + 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)o0[j] * (float)d0[j] + (float)o1[j] * (float)d1[j];
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  if (part == 0) {
+    del_s[rr] = acc;
+    lse_s[rr] = q < a.T ? a.lse[((long)b * a.H + h) * a.T + q] : 1e30f;
+  }
+}
+
+// dK, dV of one 64-key block: wave w owns key tile w; all query blocks stream through LDS
+__global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const AttnArgs a, int nkb) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 128 + 2 * 64 * 4];
+  char* Ks = smem;
+  char* Vs = Ks + 64 * 128;
+  char* Qs = Vs + 64 * 128;
+  char* Os = Qs + 64 * 128;                               // dO
+  float* lse_s = (float*)(Os + 64 * 128);
+  float* del_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int kb = blockIdx.x % nkb, bh = blockIdx.x / nkb;
+  const int b = bh / a.H, h = bh % a.H;
+  const int T = a.T;
+  const long row0 = (long)b * T;
+  stage_block64(a.k + h * 64, a.ldk, row0, 64 * kb, T, Ks, tid);
+  stage_block64(a.v + h * 64, a.ldv, row0, 64 * kb, T, Vs, tid);
+  __syncthreads();
+  const int keyl = 16 * wave + li, key = 64 * kb + keyl;
+  bool key_ok = key < T;
+  if (key_ok && a.keep) key_ok = a.keep[row0 + key] != 0.f;
+  const bf16x8 kf0 = frag_row(Ks, keyl, g), kf1 = frag_row(Ks, keyl, 4 + g);
+  const bf16x8 vf0 = frag_row(Vs, keyl, g), vf1 = frag_row(Vs, keyl, 4 + g);
+  f32x4 dvT[4], dkT[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dvT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const int nqb = (T + 63) >> 6;
+  for (int qb = a.causal ? kb : 0; qb < nqb; ++qb) {      // causal: query blocks above the diagonal see none of these keys
+    __syncthreads();
+    stage_block64(a.q + h * 64, a.ldq, row0, 64 * qb, T, Qs, tid);
+    stage_block64(a.dout + h * 64, a.lddo, row0, 64 * qb, T, Os, tid);
+    stage_lse_delta64(a, row0, b, h, 64 * qb, lse_s, del_s, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      bf16x8 pf, dsf;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * ss + half;
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int qrow = 16 * qt + li;
+        sv = CCLIP_MFMA_16x16x32(frag_row(Qs, qrow, g), kf0, sv);
+        sv = CCLIP_MFMA_16x16x32(frag_row(Qs, qrow, 4 + g), kf1, sv);
+        dp = CCLIP_MFMA_16x16x32(frag_row(Os, qrow, g), vf0, dp);
+        dp = CCLIP_MFMA_16x16x32(frag_row(Os, qrow, 4 + g), vf1, dp);
+        const float4 ls = *(const float4*)(lse_s + 16 * qt + 4 * g);
+        const float4 de = *(const float4*)(del_s + 16 * qt + 4 * g);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = 64 * qb + 16 * qt + 4 * g + r;
+          const bool ok = key_ok && (!a.causal || key <= qi);
+          const float pv = ok ? __expf(sv[r] * a.scale - lsv[r]) : 0.f;
+          pf[4 * half + r] = (bf16)pv;
+          dsf[4 * half + r] = (bf16)(pv * (dp[r] - dev[r]) * a.scale);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dvT[dt] = CCLIP_MFMA_16x16x32(frag_tr(Os, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), pf, dvT[dt]);
+        dkT[dt] = CCLIP_MFMA_16x16x32(frag_tr(Qs, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, dt, lane), dsf, dkT[dt]);
+      }
+    }
+  }
+  if (key < T) {
+    bf16* dvp = a.dv + (row0 + key) * a.lddv + h * 64 + 4 * g;
+    bf16* dkp = a.dk + (row0 + key) * a.lddk + h * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 x = {(bf16)dvT[dt][0], (bf16)dvT[dt][1], (bf16)dvT[dt][2], (bf16)dvT[dt][3]};
+      bf16x4 y = {(bf16)dkT[dt][0], (bf16)dkT[dt][1], (bf16)dkT[dt][2], (bf16)dkT[dt][3]};
+      *(bf16x4*)(dvp + 16 * dt) = x;
+      *(bf16x4*)(dkp + 16 * dt) = y;
+    }
+  }
+}
+
+// dQ of one 64-query block: wave w owns query tile w; all key blocks stream through LDS
+__global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const AttnArgs a, int nqb) {
+  constexpr int DS_LD = 2 * 64 + 16;                      // padded dS row stride (bytes)
+  __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 128 + 64 * DS_LD + 2 * 64 * 4];
+  char* Ks = smem;
+  char* Vs = Ks + 64 * 128;
+  char* Qs = Vs + 64 * 128;
+  char* Os = Qs + 64 * 128;
+  char* dSs = Os + 64 * 128;                              // [q][key] bf16
+  float* lse_s = (float*)(dSs + 64 * DS_LD);
+  float* del_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+  const int b = bh / a.H, h = bh % a.H;
+  const int T = a.T;
+  const long row0 = (long)b * T;
+  stage_block64(a.q + h * 64, a.ldq, row0, 64 * qb, T, Qs, tid);
+  stage_block64(a.dout + h * 64, a.lddo, row0, 64 * qb, T, Os, tid);
+  stage_lse_delta64(a, row0, b, h, 64 * qb, lse_s, del_s, tid);
+  f32x4 dqT[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dqT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int nkb = (T + 63) >> 6;
+  if (a.causal && qb + 1 < nkb) nkb = qb + 1;
+  const int qrow = 16 * wave + li;                        // this lane's query row as an A-operand row (S, dP)
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();                                      // previous block's dS / K readers are done
+    stage_block64(a.k + h * 64, a.ldk, row0, 64 * kb, T, Ks, tid);
+    stage_block64(a.v + h * 64, a.ldv, row0, 64 * kb, T, Vs, tid);
+    __syncthreads();
+    const float4 ls = *(const float4*)(lse_s + 16 * wave + 4 * g);
+    const float4 de = *(const float4*)(del_s + 16 * wave + 4 * g);
+    const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int keyl = 16 * kt + li, key = 64 * kb + keyl;
+      bool key_ok = key < T;
+      if (key_ok && a.keep) key_ok = a.keep[row0 + key] != 0.f;
+      f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+      sv = CCLIP_MFMA_16x16x32(frag_row(Qs, qrow, g), frag_row(Ks, keyl, g), sv);
+      sv = CCLIP_MFMA_16x16x32(frag_row(Qs, qrow, 4 + g), frag_row(Ks, keyl, 4 + g), sv);
+      dp = CCLIP_MFMA_16x16x32(frag_row(Os, qrow, g), frag_row(Vs, keyl, g), dp);
+      dp = CCLIP_MFMA_16x16x32(frag_row(Os, qrow, 4 + g), frag_row(Vs, keyl, 4 + g), dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * wave + 4 * g + r, qi = 64 * qb + ql;
+        const bool ok = key_ok && (!a.causal || key <= qi);
+        const float pv = ok ? __expf(sv[r] * a.scale - lsv[r]) : 0.f;
+        *(bf16*)(dSs + ql * DS_LD + keyl * 2) = (bf16)(pv * (dp[r] - dev[r]) * a.scale);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                      // dS rows of this wave's query tile are written and read by the same wave
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const bf16x8 dsf = *(const bf16x8*)(dSs + qrow * DS_LD + (32 * ss + 8 * g) * 2);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dqT[dt] = CCLIP_MFMA_16x16x32(frag_tr(Ks, 32 * ss + 8 * g, 32 * ss + 8 * g + 4, dt, lane), dsf, dqT[dt]);
+    }
+  }
+  const int qi = 64 * qb + qrow;
+  if (qi < T) {
+    bf16* dqp = a.dq + (row0 + qi) * a.lddq + h * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 x = {(bf16)dqT[dt][0], (bf16)dqT[dt][1], (bf16)dqT[dt][2], (bf16)dqT[dt][3]};
+      *(bf16x4*)(dqp + 16 * dt) = x;
+    }
+  }
+}
+
 }  // namespace CCLIP_NS
 using namespace CCLIP_NS;
 
 static bool attn_args_ok(const cclip_attn_desc* d, bool bwd) {
   if (!d || !d->q || !d->k || !d->v || !d->o) return false;
-  if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->T > (bwd ? 128 : 8192) || d->head_dim != 64) return false;
+  if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->T > 8192 || d->head_dim != 64) return false;
   if ((d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7)) return false;
   if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->o) & 15) return false;
   if (bwd) {
@@ -481,6 +668,12 @@ extern "C" int CCLIP_FN(cclip_attention_bwd)(const cclip_attn_desc* d, hipStream
   const AttnArgs a = attn_pack(d);
   dim3 grid(d->B * d->H), block(256);
   const int nkt = (d->T + 15) / 16;
+  if (d->T > 128) {
+    const int nb64 = (d->T + 63) / 64;
+    hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, dim3(d->B * d->H * nb64), block, 0, stream, a, nb64);
+    hipLaunchKernelGGL(attn_long_bwd_dq_kernel, dim3(d->B * d->H * nb64), block, 0, stream, a, nb64);
+    return cclip_launch_status();
+  }
   if (nkt <= 2) hipLaunchKernelGGL((attn_bwd_kernel<2>), grid, block, 0, stream, a);
   else if (nkt <= 4) hipLaunchKernelGGL((attn_bwd_kernel<4>), grid, block, 0, stream, a);
   else if (nkt <= 6) hipLaunchKernelGGL((attn_bwd_kernel<6>), grid, block, 0, stream, a);

@@ -105,9 +105,9 @@ int cclip_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const 
                         void* dx_out_bf16, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                         float* ws, hipStream_t stream);
 
-/* ---- fused multi-head attention, head_dim 64; forward any T <= 8192, backward T <= 128 -------
+/* ---- fused multi-head attention, head_dim 64, T <= 8192, forward and backward ------------------
  * (T > 128 - ViT-B/16 197, ViT-L/14 257, ViT-L/14@336px 577 tokens - runs the key-block-tiled
- * online-softmax forward.)  Replaces softmax(q k^T * scale + mask) v of nn.MultiheadAttention (CLIP towers; causal for the
+ * online-softmax forward and a two-launch backward: dK/dV per key block, dQ per query block.)  Replaces softmax(q k^T * scale + mask) v of nn.MultiheadAttention (CLIP towers; causal for the
  * text tower) and of GPT-2 (causal + key padding).  q/k/v/o/d*: bf16, row (b*T + t), head h at
  * column h*64 of the given base pointer (so a packed [B*T, 3D] qkv buffer is passed as three
  * offset pointers with the same row stride).  lse: fp32 [B,H,T] written by fwd, read by bwd.

@@ -124,7 +124,7 @@ def main():
     torch.save(clip_case("test-tiny", 9, 11, True), os.path.join(OUT, "clip_test_tiny.pt"))
     torch.save(clip_case("test-small", 9, 12, True), os.path.join(OUT, "clip_test_small.pt"))
     torch.save(clip_case("ViT-B/32", 9, 567, False), os.path.join(OUT, "clip_vit_b32.pt"))
-    torch.save(clip_case("test-long", 9, 13, False), os.path.join(OUT, "clip_test_long.pt"))
+    torch.save(clip_case("test-long", 9, 13, True), os.path.join(OUT, "clip_test_long.pt"))
     torch.save(image_only_case("ViT-L/14@336px", 2, 567), os.path.join(OUT, "clip_vit_l14_336.pt"))
     torch.save(caption_case("test-tiny", 3, 12, 21), os.path.join(OUT, "caption_test_tiny.pt"))
     torch.save(caption_tmapper_case("test-tiny", 3, 12, 23, clip_length=6, num_layers=2), os.path.join(OUT, "caption_tmapper_tiny.pt"))
