@@ -76,6 +76,7 @@ class GemmDesc(ctypes.Structure):
         ("out_f32", c_void_p), ("out_bf16", c_void_p), ("out_pre_bf16", c_void_p), ("ldc", c_long),
         ("split_k", c_int), ("split_ws", c_void_p),
         ("tile_config", c_int),
+        ("colsum_out", c_void_p), ("colsum_accumulate", c_int),
     ]
 
 
@@ -113,6 +114,11 @@ def _autotune(d, key, outs, candidates):
     """candidates: list of (tile_config, split_k).  Outputs are redirected to scratch so that in-place residual
     GEMMs (x += ...) are not applied more than once."""
     saved = (d.out_f32, d.out_bf16, d.out_pre_bf16, d.tile_config, d.split_k, d.split_ws)
+    saved_cs = (d.colsum_out, d.colsum_accumulate)
+    cs_tmp = None
+    if d.colsum_out:                        # trial launches must not touch (or accumulate into) the real bias gradient
+        cs_tmp = torch.empty(d.M, device="cuda", dtype=torch.float32)
+        d.colsum_out, d.colsum_accumulate = cs_tmp.data_ptr(), 0
     # scratch outputs with the SAME row stride as the real ones (outputs are often column slices of a wider slab)
     tmp = [torch.empty((d.M, d.ldc), device=t.device, dtype=t.dtype) if t is not None else None for t in outs]
     d.out_f32 = 0 if tmp[0] is None else tmp[0].data_ptr()
@@ -123,7 +129,7 @@ def _autotune(d, key, outs, candidates):
     for cfg, sp in candidates:
         d.tile_config, d.split_k = cfg, sp
         if sp > 1:
-            need = sp * d.M * d.N
+            need = sp * d.M * (d.N + 1)
             if ws is None or ws.numel() < need:
                 ws = torch.empty(need, device=outs[0].device if outs[0] is not None else "cuda", dtype=torch.float32)
             d.split_ws = ws.data_ptr()
@@ -134,6 +140,7 @@ def _autotune(d, key, outs, candidates):
         if t < best_t:
             best, best_t = (cfg, sp), t
     d.out_f32, d.out_bf16, d.out_pre_bf16, d.tile_config, d.split_k, d.split_ws = saved
+    d.colsum_out, d.colsum_accumulate = saved_cs
     _TUNED[key] = best
     return best
 
@@ -144,11 +151,13 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
               out_f32: Optional[torch.Tensor] = None, out_bf16: Optional[torch.Tensor] = None,
               out_pre: Optional[torch.Tensor] = None, split_k: int = 1,
               split_ws: Optional[torch.Tensor] = None, M: Optional[int] = None, tile_config: int = 0,
-              split_candidates=None, scratch=None) -> None:
+              split_candidates=None, scratch=None, colsum_out: Optional[torch.Tensor] = None,
+              colsum_accumulate: bool = False) -> None:
     """C[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see cclip_gemm_bf16 in include/cclip_hip.h.
     A: [M,K] (a_kcontig) or [K,M]; B: [N,K] (b_kcontig) or [K,N]; 2-D, inner stride 1.
     split_candidates (wgrad): list of (tile_config, split_k) to autotune over; `scratch(n)` returns an fp32
-    workspace of n floats for the chosen split."""
+    workspace of n floats for the chosen split.
+    colsum_out (wgrad layout only): fp32 [M] (+)= sum_k A(m,k) - the bias gradient, fused into the weight-gradient GEMM."""
     _req16(A, "A"); _req16(B, "B")
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     Mx, K = (A.shape[0], A.shape[1]) if a_kcontig else (A.shape[1], A.shape[0])
@@ -182,6 +191,10 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     d.split_k = split_k
     d.split_ws = 0 if split_ws is None else split_ws.data_ptr()
     d.tile_config = tile_config
+    if colsum_out is not None:
+        _req(colsum_out, torch.float32, "colsum_out")
+        assert not a_kcontig and not b_kcontig and colsum_out.numel() == M and colsum_out.is_contiguous()
+        d.colsum_out, d.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
     if bias is not None:
         _req(bias, torch.float32, "bias")
     if residual is not None:
@@ -190,7 +203,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
         _req(out_f32, torch.float32, "out_f32")
     if tile_config == 0 and AUTOTUNE and 2.0 * M * N * K >= _TUNE_MIN_FLOPS and (outs[0].is_contiguous() or True):
         key = (A.dtype, M, N, K, a_kcontig, b_kcontig, act, out_f32 is not None, out_bf16 is not None, out_pre is not None,
-               residual is not None, bias is not None, split_k if split_candidates is None else -1)
+               residual is not None, bias is not None, split_k if split_candidates is None else -1, colsum_out is not None)
         choice = _TUNED.get(key)
         if choice is None:
             cands = split_candidates if split_candidates is not None else [(1, split_k), (2, split_k), (3, split_k), (4, split_k)]
@@ -199,7 +212,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
             choice = _autotune(d, key, outs3, cands)
         d.tile_config, d.split_k = choice
         if d.split_k > 1 and split_candidates is not None:
-            ws = scratch(d.split_k * M * N)
+            ws = scratch(d.split_k * M * (N + 1))
             d.split_ws = ws.data_ptr()
     if d.split_k > 1:
         assert d.split_ws, "split_k > 1 needs a workspace"

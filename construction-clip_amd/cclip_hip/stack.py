@@ -225,12 +225,19 @@ class BlockStack:
         return x
 
     # ------------------------------------------------------------------ backward
-    def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool, scratch=None):
-        """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out]."""
+    def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool, scratch=None,
+               gb: Optional[torch.Tensor] = None, acc_b: bool = False):
+        """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out].
+        gb: the layer's bias gradient (+)= column sums of dy.  With nn.Linear weights dy^T is the GEMM's A operand and the
+        sums ride on the same launch (one extra MFMA per m-tile in the first column block of tiles); otherwise colsum."""
         a, b = (dy, xin) if self.geo.linear_layout else (xin, dy)
         n_out, k_in = gw.shape
+        fused = gb is not None and self.geo.linear_layout
         ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
-                      split_candidates=wgrad_candidates(n_out, k_in, M), scratch=(scratch or self.scratch).floats)
+                      split_candidates=wgrad_candidates(n_out, k_in, M), scratch=(scratch or self.scratch).floats,
+                      colsum_out=gb if fused else None, colsum_accumulate=acc_b)
+        if gb is not None and not fused:
+            self._bgrad(dy, gb, M, acc_b, scratch)
 
     def _bgrad(self, dy: torch.Tensor, gb: torch.Tensor, M: int, acc: bool, scratch=None):
         C = gb.numel()
@@ -308,14 +315,12 @@ class BlockStack:
             # ---- MLP branch ----
             if gr is not None:
                 def f1(sc, dxb=dxb, g=g, gr=gr):
-                    self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc)
-                    self._bgrad(dxb, gr["b_proj"], M, A("b_proj", gr), sc)
+                    self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
                 leaf(f1)
             ops.gemm_bf16(dxb, w.w_proj, b_kcontig=not kc, act=dact, aux=h, out_bf16=dh, M=M)
             if gr is not None:
                 def f2(sc, dh=dh, xn2=xn2, gr=gr):
-                    self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc)
-                    self._bgrad(dh, gr["b_fc"], M, A("b_fc", gr), sc)
+                    self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
                 leaf(f2)
             ops.gemm_bf16(dh, w.w_fc, b_kcontig=not kc, out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
@@ -326,8 +331,7 @@ class BlockStack:
             # ---- attention branch ----
             if gr is not None:
                 def f3(sc, dxb=dxb, a=a, gr=gr):
-                    self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc)
-                    self._bgrad(dxb, gr["b_o"], M, A("b_o", gr), sc)
+                    self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
                 leaf(f3)
             ops.gemm_bf16(dxb, w.w_o, b_kcontig=not kc, out_bf16=dsm, M=M)
             if geo.head_dim == 64:
@@ -339,9 +343,8 @@ class BlockStack:
                                         dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, head_dim=geo.head_dim)
             if gr is not None:
                 def f4(sc, dqkv=dqkv, xn1=xn1, gr=gr):
-                    self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc)
-                    if gr.get("b_qkv") is not None:          # TransformerMapper's q / kv projections have no bias
-                        self._bgrad(dqkv, gr["b_qkv"], M, A("b_qkv", gr), sc)
+                    gbq = gr.get("b_qkv")                    # TransformerMapper's q / kv projections have no bias
+                    self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc, gbq, A("b_qkv", gr) if gbq is not None else False)
                 leaf(f4)
             ops.gemm_bf16(dqkv, w.w_qkv, b_kcontig=not kc, out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None

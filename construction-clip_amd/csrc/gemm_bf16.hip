@@ -40,7 +40,15 @@ bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmAr
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
                                                             float alpha, const float* __restrict__ residual, long ldr,
-                                                            float* __restrict__ out_f32, bf16* __restrict__ out_bf16, long ldc) {
+                                                            float* __restrict__ out_f32, bf16* __restrict__ out_bf16, long ldc,
+                                                            const float* __restrict__ cs_ws, float* __restrict__ cs_dst, int cs_acc) {
+  if (cs_dst) {                                            // fused bias gradient: sum the per-split row sums
+    for (long m = blockIdx.x * 256L + threadIdx.x; m < M; m += (long)gridDim.x * 256L) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += cs_ws[(long)z * M + m];
+      cs_dst[m] = (cs_acc ? cs_dst[m] : 0.f) + s;
+    }
+  }
   const long total = (long)M * N / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -94,13 +102,18 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   a.aux = (const bf16*)d->aux; a.ldaux = d->ldaux;
   a.out_f32 = d->out_f32; a.out_bf16 = (bf16*)d->out_bf16; a.out_pre = (bf16*)d->out_pre_bf16; a.ldc = d->ldc;
   a.act = d->act; a.split_ws = splits > 1 ? d->split_ws : nullptr;
+  if (d->colsum_out) {
+    if (d->a_kcontig || d->b_kcontig) return CCLIP_ERR_ARG;     // row sums of A ride on the wgrad layout only
+    a.colsum_dst = d->colsum_out; a.colsum_acc = d->colsum_accumulate;
+    a.colsum_ws = splits > 1 ? d->split_ws + (size_t)splits * d->M * d->N : nullptr;
+  }
 #ifdef CCLIP_GEMM_STAMPS
   a.stamps = g_stamps;
 #endif
 
   int cfg = d->tile_config;
   // M <= 8 against K-strided weights (the projections of a KV-cached decode step): weight-read-bound GEMV path
-  if (cfg == 0 && splits == 1 && d->M <= 8 && cclip_gemm_launch_skinny(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a))
+  if (cfg == 0 && splits == 1 && d->M <= 8 && !d->colsum_out && cclip_gemm_launch_skinny(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a))
     return cclip_launch_status();
   if (cfg == 4) {     // persistent streaming-epilogue kernel: forward layout, full tiles only - refused (not silently replaced) otherwise
     if (splits > 1 || !cclip_gemm_launch_cfg4(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
@@ -122,7 +135,7 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     long total = (long)d->M * d->N / 4;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d->split_ws, splits, d->M, d->N,
-                       d->alpha, d->residual, d->ldr, d->out_f32, (bf16*)d->out_bf16, d->ldc);
+                       d->alpha, d->residual, d->ldr, d->out_f32, (bf16*)d->out_bf16, d->ldc, a.colsum_ws, a.colsum_dst, a.colsum_acc);
     st = cclip_launch_status();
   }
   return st;

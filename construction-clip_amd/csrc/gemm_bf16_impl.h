@@ -28,6 +28,9 @@ struct GemmArgs {
   // [kv_width, 3*kv_width) of the output also go to the KV cache row of each sequence
   const float* ln_x = nullptr; long ln_ldx = 0; const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
   bf16* kv_k = nullptr; bf16* kv_v = nullptr; long kv_ld_seq = 0; int kv_width = 0;
+  // wgrad layout only: row sums of A over K (= the bias gradient of the layer whose weight gradient this GEMM is);
+  // with split-K the raw partials go to colsum_ws[z][M] and the combine kernel finishes them
+  float* colsum_dst = nullptr; float* colsum_ws = nullptr; int colsum_acc = 0;
 #ifdef CCLIP_GEMM_STAMPS
   unsigned long long* stamps;   // diagnostics build only: [tile][8] = hw id, t_start, t_issued, t_first, t_kdone, t_end (100 MHz)
 #endif
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   // valid), they land under the K loop's MFMA phase, and the epilogue is left with math and fire-and-forget
   // stores - one full memory round trip per tile and half of the epilogue's HBM traffic leave the serial path.
   constexpr bool HAS_AUX = ACT >= CCLIP_ACT_DQUICKGELU;
-  constexpr bool PRE = MT <= 4;
+  constexpr bool PRE = MT <= 4 && (A_KC || B_KC);          // (the wgrad layout spends those registers on the fused bias gradient)
   constexpr int EB = PRE ? MT : 2;                               // m-tiles per epilogue batch (register budget)
   const int li = lane & 15, g = lane >> 4;
   float rres[EB][2][8];
@@ -261,12 +264,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   }
   STAMP(2);
   int cur = 0;                                                   // stage holding tile kt
+  constexpr bool WG_LAYOUT = !A_KC && !B_KC && MT <= 4;     // (the 128x64-per-wave kernels have no registers left for it)
+  f32x4 accb[WG_LAYOUT ? MT : 1];
+  bf16x8 ones8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones8[j] = (bf16)1.0f;
+#pragma unroll
+  for (int i = 0; i < (WG_LAYOUT ? MT : 1); ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // One K-tile iteration.  DMA = true (steady state, kt + PD < kt1): the operand DMA of tile kt+PD is part of the same
   // basic block as the MFMAs and is dealt out BETWEEN them (one global_load_lds per few MFMAs): issuing the 6-8 DMA
   // instructions back to back cost ~500 clocks per wave per iteration with the matrix pipe idle (in-kernel stamps,
   // tools/gemm_stamps.py), almost as much as the iteration's MFMAs themselves.  DMA = false: the last PD iterations.
-  auto k_iter = [&](int kt, auto dma_tag, int wait_tiles) {
+  auto k_iter = [&](int kt, auto dma_tag, auto cs_tag, int wait_tiles) {
     constexpr bool DMA = decltype(dma_tag)::value;
+    constexpr bool CS = decltype(cs_tag)::value;
     // In-process A/B against the previous build (tools/gemm_ab.py, MI355X): dealing the DMA out between k-step 1's
     // MFMAs (ILV) is worth -14..-34 % on the K-strided layouts of the 8-wave configurations (dgrad / wgrad: twice the
     // LDS read instructions) and -2..-7 % with 3 stages, but +5..10 % on 2-stage forward-layout kernels, whose DMA
@@ -336,6 +347,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
+      if (CS) {     // row sums of A: one more MFMA per m-tile against an all-ones fragment (every output row then holds the sum)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accb[mt] = CCLIP_MFMA_16x16x32(ones8, xf[ks][mt], accb[mt]);
+      }
     }
     // schedule: the LDS reads of k-step 0 up front; k-step 1's fragments stream in between k-step 0's MFMAs; the DMA
     // instructions of tile kt+PD go between k-step 1's MFMAs
@@ -375,8 +390,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   };
   int kt = kt0;
-  for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, PD - 1);
-  for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, kt1 - 1 - kt);
+  bool cs = false;
+  if constexpr (WG_LAYOUT) {
+    cs = p.colsum_dst != nullptr && bn0 == 0;             // one column block of tiles carries the bias gradient
+    if (cs) {
+      for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::true_type{}, PD - 1);
+      for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::true_type{}, kt1 - 1 - kt);
+    }
+  }
+  if (!cs) {
+    for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::false_type{}, PD - 1);
+    for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::false_type{}, kt1 - 1 - kt);
+  }
+  if constexpr (WG_LAYOUT) {
+    if (cs && wn == 0 && (lane >> 4) == 0) {              // D[any row][col li] = sum_k A(16 mt + li, k): take row 0
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = bm0 + wm0 + 16 * mt + (lane & 15);
+        if (m < p.M) {
+          if (p.split_ws) p.colsum_ws[(long)blockIdx.y * p.M + m] = accb[mt][0];
+          else p.colsum_dst[m] = (p.colsum_acc ? p.colsum_dst[m] : 0.f) + accb[mt][0];
+        }
+      }
+    }
+  }
 
   STAMP(4);
   // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
@@ -463,6 +500,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 template <int WM, int WN, int STAGES, int MT>
 static bool gemm_launch_cfg(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a) {
   dim3 block(64 * WM * WN);
+  if (a.colsum_dst && MT > 4) return false;                 // fused bias gradient: 64x64-per-wave configurations only
 #define LAUNCH(AK, BKC, ACTV) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, ACTV, WM, WN, STAGES, MT>), grid, block, 0, stream, a)
   if (lay == 3) {
     switch (act) {

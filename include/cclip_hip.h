@@ -27,7 +27,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define CCLIP_ABI_VERSION 1
+#define CCLIP_ABI_VERSION 2
 int cclip_abi_version(void);
 
 /* ---- epilogue activations (forward and their backward forms) ---- */
@@ -82,6 +82,11 @@ typedef struct cclip_gemm_desc {
                         *     M % 256 == 0, N % 128 == 0, N <= 4096, K >= 512 (640 with a residual), one of the three
                         *     epilogue forms {16-bit out | pre-activation + activation | fp32 out + residual}; status 1 otherwise.
                         * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
+  /* wgrad layout (0,0) only: colsum_out[m] (+)= sum_k A(m,k) - the BIAS gradient of the layer whose weight gradient this
+   * call computes (A = dY^T), taken off the operand tiles already in LDS by one extra MFMA per m-tile against an all-ones
+   * fragment in the first column block of tiles.  With split_k > 1 split_ws must hold split_k*M*(N+1) floats. */
+  float* colsum_out;
+  int32_t colsum_accumulate;
 } cclip_gemm_desc;
 int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream);
 
