@@ -4,7 +4,7 @@ import ctypes
 import os
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcclip_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

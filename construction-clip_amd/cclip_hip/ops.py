@@ -76,7 +76,7 @@ class GemmDesc(ctypes.Structure):
         ("out_f32", c_void_p), ("out_bf16", c_void_p), ("out_pre_bf16", c_void_p), ("ldc", c_long),
         ("split_k", c_int), ("split_ws", c_void_p),
         ("tile_config", c_int),
-        ("colsum_out", c_void_p), ("colsum_accumulate", c_int),
+        ("colsum_out", c_void_p), ("colsum_accumulate", c_int), ("colsum_of_b", c_int),
     ]
 
 
@@ -117,7 +117,7 @@ def _autotune(d, key, outs, candidates):
     saved_cs = (d.colsum_out, d.colsum_accumulate)
     cs_tmp = None
     if d.colsum_out:                        # trial launches must not touch (or accumulate into) the real bias gradient
-        cs_tmp = torch.empty(d.M, device="cuda", dtype=torch.float32)
+        cs_tmp = torch.empty(max(d.M, d.N), device="cuda", dtype=torch.float32)
         d.colsum_out, d.colsum_accumulate = cs_tmp.data_ptr(), 0
     # scratch outputs with the SAME row stride as the real ones (outputs are often column slices of a wider slab)
     tmp = [torch.empty((d.M, d.ldc), device=t.device, dtype=t.dtype) if t is not None else None for t in outs]
@@ -129,7 +129,7 @@ def _autotune(d, key, outs, candidates):
     for cfg, sp in candidates:
         d.tile_config, d.split_k = cfg, sp
         if sp > 1:
-            need = sp * d.M * (d.N + 1)
+            need = sp * (d.M * d.N + max(d.M, d.N))
             if ws is None or ws.numel() < need:
                 ws = torch.empty(need, device=outs[0].device if outs[0] is not None else "cuda", dtype=torch.float32)
             d.split_ws = ws.data_ptr()
@@ -152,12 +152,13 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
               out_pre: Optional[torch.Tensor] = None, split_k: int = 1,
               split_ws: Optional[torch.Tensor] = None, M: Optional[int] = None, tile_config: int = 0,
               split_candidates=None, scratch=None, colsum_out: Optional[torch.Tensor] = None,
-              colsum_accumulate: bool = False) -> None:
+              colsum_accumulate: bool = False, colsum_of_b: bool = False) -> None:
     """C[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see cclip_gemm_bf16 in include/cclip_hip.h.
     A: [M,K] (a_kcontig) or [K,M]; B: [N,K] (b_kcontig) or [K,N]; 2-D, inner stride 1.
     split_candidates (wgrad): list of (tile_config, split_k) to autotune over; `scratch(n)` returns an fp32
     workspace of n floats for the chosen split.
-    colsum_out (wgrad layout only): fp32 [M] (+)= sum_k A(m,k) - the bias gradient, fused into the weight-gradient GEMM."""
+    colsum_out (wgrad layout only): fp32 [M] (+)= sum_k A(m,k), or with colsum_of_b fp32 [N] (+)= sum_k B(n,k) - the bias
+    gradient, fused into the weight-gradient GEMM."""
     _req16(A, "A"); _req16(B, "B")
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     Mx, K = (A.shape[0], A.shape[1]) if a_kcontig else (A.shape[1], A.shape[0])
@@ -193,8 +194,8 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     d.tile_config = tile_config
     if colsum_out is not None:
         _req(colsum_out, torch.float32, "colsum_out")
-        assert not a_kcontig and not b_kcontig and colsum_out.numel() == M and colsum_out.is_contiguous()
-        d.colsum_out, d.colsum_accumulate = colsum_out.data_ptr(), int(colsum_accumulate)
+        assert not a_kcontig and not b_kcontig and colsum_out.numel() == (N if colsum_of_b else M) and colsum_out.is_contiguous()
+        d.colsum_out, d.colsum_accumulate, d.colsum_of_b = colsum_out.data_ptr(), int(colsum_accumulate), int(colsum_of_b)
     if bias is not None:
         _req(bias, torch.float32, "bias")
     if residual is not None:
@@ -203,7 +204,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
         _req(out_f32, torch.float32, "out_f32")
     if tile_config == 0 and AUTOTUNE and 2.0 * M * N * K >= _TUNE_MIN_FLOPS and (outs[0].is_contiguous() or True):
         key = (A.dtype, M, N, K, a_kcontig, b_kcontig, act, out_f32 is not None, out_bf16 is not None, out_pre is not None,
-               residual is not None, bias is not None, split_k if split_candidates is None else -1, colsum_out is not None)
+               residual is not None, bias is not None, split_k if split_candidates is None else -1, colsum_out is not None, colsum_of_b)
         choice = _TUNED.get(key)
         if choice is None:
             cands = split_candidates if split_candidates is not None else [(1, split_k), (2, split_k), (3, split_k), (4, split_k)]
@@ -212,7 +213,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
             choice = _autotune(d, key, outs3, cands)
         d.tile_config, d.split_k = choice
         if d.split_k > 1 and split_candidates is not None:
-            ws = scratch(d.split_k * M * (N + 1))
+            ws = scratch(d.split_k * (M * N + max(M, N)))
             d.split_ws = ws.data_ptr()
     if d.split_k > 1:
         assert d.split_ws, "split_k > 1 needs a workspace"

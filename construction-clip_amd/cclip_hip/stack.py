@@ -228,16 +228,15 @@ class BlockStack:
     def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool, scratch=None,
                gb: Optional[torch.Tensor] = None, acc_b: bool = False):
         """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out].
-        gb: the layer's bias gradient (+)= column sums of dy.  With nn.Linear weights dy^T is the GEMM's A operand and the
-        sums ride on the same launch (one extra MFMA per m-tile in the first column block of tiles); otherwise colsum."""
-        a, b = (dy, xin) if self.geo.linear_layout else (xin, dy)
+        gb: the layer's bias gradient (+)= column sums of dy: dy is an operand of this GEMM (A for nn.Linear weights, B for
+        Conv1D ones), so the sums ride on the same launch - one extra MFMA per tile row / column against an all-ones fragment
+        in the first block of tiles."""
+        lin = self.geo.linear_layout
+        a, b = (dy, xin) if lin else (xin, dy)
         n_out, k_in = gw.shape
-        fused = gb is not None and self.geo.linear_layout
         ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
                       split_candidates=wgrad_candidates(n_out, k_in, M), scratch=(scratch or self.scratch).floats,
-                      colsum_out=gb if fused else None, colsum_accumulate=acc_b)
-        if gb is not None and not fused:
-            self._bgrad(dy, gb, M, acc_b, scratch)
+                      colsum_out=gb, colsum_accumulate=acc_b, colsum_of_b=not lin)
 
     def _bgrad(self, dy: torch.Tensor, gb: torch.Tensor, M: int, acc: bool, scratch=None):
         C = gb.numel()

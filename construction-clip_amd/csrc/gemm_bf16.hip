@@ -41,11 +41,11 @@ bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmAr
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
                                                             float alpha, const float* __restrict__ residual, long ldr,
                                                             float* __restrict__ out_f32, bf16* __restrict__ out_bf16, long ldc,
-                                                            const float* __restrict__ cs_ws, float* __restrict__ cs_dst, int cs_acc) {
+                                                            const float* __restrict__ cs_ws, float* __restrict__ cs_dst, int cs_acc, int cs_len) {
   if (cs_dst) {                                            // fused bias gradient: sum the per-split row sums
-    for (long m = blockIdx.x * 256L + threadIdx.x; m < M; m += (long)gridDim.x * 256L) {
+    for (long m = blockIdx.x * 256L + threadIdx.x; m < cs_len; m += (long)gridDim.x * 256L) {
       float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += cs_ws[(long)z * M + m];
+      for (int z = 0; z < splits; ++z) s += cs_ws[(long)z * cs_len + m];
       cs_dst[m] = (cs_acc ? cs_dst[m] : 0.f) + s;
     }
   }
@@ -104,7 +104,7 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   a.act = d->act; a.split_ws = splits > 1 ? d->split_ws : nullptr;
   if (d->colsum_out) {
     if (d->a_kcontig || d->b_kcontig) return CCLIP_ERR_ARG;     // row sums of A ride on the wgrad layout only
-    a.colsum_dst = d->colsum_out; a.colsum_acc = d->colsum_accumulate;
+    a.colsum_dst = d->colsum_out; a.colsum_acc = d->colsum_accumulate; a.colsum_b = d->colsum_of_b ? 1 : 0;
     a.colsum_ws = splits > 1 ? d->split_ws + (size_t)splits * d->M * d->N : nullptr;
   }
 #ifdef CCLIP_GEMM_STAMPS
@@ -135,7 +135,7 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     long total = (long)d->M * d->N / 4;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d->split_ws, splits, d->M, d->N,
-                       d->alpha, d->residual, d->ldr, d->out_f32, (bf16*)d->out_bf16, d->ldc, a.colsum_ws, a.colsum_dst, a.colsum_acc);
+                       d->alpha, d->residual, d->ldr, d->out_f32, (bf16*)d->out_bf16, d->ldc, a.colsum_ws, a.colsum_dst, a.colsum_acc, a.colsum_b ? d->N : d->M);
     st = cclip_launch_status();
   }
   return st;

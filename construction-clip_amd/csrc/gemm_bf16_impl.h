@@ -31,6 +31,7 @@ struct GemmArgs {
   // wgrad layout only: row sums of A over K (= the bias gradient of the layer whose weight gradient this GEMM is);
   // with split-K the raw partials go to colsum_ws[z][M] and the combine kernel finishes them
   float* colsum_dst = nullptr; float* colsum_ws = nullptr; int colsum_acc = 0;
+  int colsum_b = 0;   // 1: row sums of B (size N) instead - the Conv1D weight layout, where dY is the B operand
 #ifdef CCLIP_GEMM_STAMPS
   unsigned long long* stamps;   // diagnostics build only: [tile][8] = hw id, t_start, t_issued, t_first, t_kdone, t_end (100 MHz)
 #endif
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   // tools/gemm_stamps.py), almost as much as the iteration's MFMAs themselves.  DMA = false: the last PD iterations.
   auto k_iter = [&](int kt, auto dma_tag, auto cs_tag, int wait_tiles) {
     constexpr bool DMA = decltype(dma_tag)::value;
-    constexpr bool CS = decltype(cs_tag)::value;
+    constexpr int CS = decltype(cs_tag)::value;            // 0: none; 1: row sums of A; 2: row sums of B
     // In-process A/B against the previous build (tools/gemm_ab.py, MI355X): dealing the DMA out between k-step 1's
     // MFMAs (ILV) is worth -14..-34 % on the K-strided layouts of the 8-wave configurations (dgrad / wgrad: twice the
     // LDS read instructions) and -2..-7 % with 3 stages, but +5..10 % on 2-stage forward-layout kernels, whose DMA
@@ -347,9 +348,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
-      if (CS) {     // row sums of A: one more MFMA per m-tile against an all-ones fragment (every output row then holds the sum)
+      if (CS == 1) {     // row sums of A: one more MFMA per m-tile against an all-ones fragment (every output row then holds the sum)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) accb[mt] = CCLIP_MFMA_16x16x32(ones8, xf[ks][mt], accb[mt]);
+      }
+      if (CS == 2) {     // row sums of B: ones on the other side (every output column then holds the sum)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) accb[nt] = CCLIP_MFMA_16x16x32(wf[ks][nt], ones8, accb[nt]);
       }
     }
     // schedule: the LDS reads of k-step 0 up front; k-step 1's fragments stream in between k-step 0's MFMAs; the DMA
@@ -390,20 +395,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   };
   int kt = kt0;
-  bool cs = false;
+  int cs = 0;
   if constexpr (WG_LAYOUT) {
-    cs = p.colsum_dst != nullptr && bn0 == 0;             // one column block of tiles carries the bias gradient
-    if (cs) {
-      for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::true_type{}, PD - 1);
-      for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::true_type{}, kt1 - 1 - kt);
+    // one column block (A sums) / one row block (B sums) of tiles carries the bias gradient
+    if (p.colsum_dst) cs = p.colsum_b ? (bm0 == 0 ? 2 : 0) : (bn0 == 0 ? 1 : 0);
+    if (cs == 1) {
+      for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::integral_constant<int, 1>{}, PD - 1);
+      for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::integral_constant<int, 1>{}, kt1 - 1 - kt);
+    } else if (cs == 2) {
+      for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::integral_constant<int, 2>{}, PD - 1);
+      for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::integral_constant<int, 2>{}, kt1 - 1 - kt);
     }
   }
-  if (!cs) {
-    for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::false_type{}, PD - 1);
-    for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::false_type{}, kt1 - 1 - kt);
+  if (cs == 0) {
+    for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::integral_constant<int, 0>{}, PD - 1);
+    for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::integral_constant<int, 0>{}, kt1 - 1 - kt);
   }
   if constexpr (WG_LAYOUT) {
-    if (cs && wn == 0 && (lane >> 4) == 0) {              // D[any row][col li] = sum_k A(16 mt + li, k): take row 0
+    if (cs == 1 && wn == 0 && (lane >> 4) == 0) {         // D[any row][col li] = sum_k A(16 mt + li, k): take row 0
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = bm0 + wm0 + 16 * mt + (lane & 15);
@@ -412,6 +421,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
           else p.colsum_dst[m] = (p.colsum_acc ? p.colsum_dst[m] : 0.f) + accb[mt][0];
         }
       }
+    }
+    if (cs == 2 && wm == 0 && (lane & 15) == 0) {         // D[row 4g + r][any col] = sum_k B(n, k), n by the n-permutation
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = bn0 + wn0 + 32 * (nt >> 1) + 8 * (lane >> 4) + 4 * (nt & 1) + r;
+          if (n < p.N) {
+            if (p.split_ws) p.colsum_ws[(long)blockIdx.y * p.N + n] = accb[nt][r];
+            else p.colsum_dst[n] = (p.colsum_acc ? p.colsum_dst[n] : 0.f) + accb[nt][r];
+          }
+        }
     }
   }
 

@@ -27,7 +27,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define CCLIP_ABI_VERSION 2
+#define CCLIP_ABI_VERSION 3
 int cclip_abi_version(void);
 
 /* ---- epilogue activations (forward and their backward forms) ---- */
@@ -87,6 +87,8 @@ typedef struct cclip_gemm_desc {
    * fragment in the first column block of tiles.  With split_k > 1 split_ws must hold split_k*M*(N+1) floats. */
   float* colsum_out;
   int32_t colsum_accumulate;
+  int32_t colsum_of_b;   /* 1: colsum_out[n] (+)= sum_k B(n,k) instead (size N; first ROW block of tiles) - the Conv1D weight layout,
+                          * where dY is the B operand of the weight-gradient GEMM; workspace split_k*(M*N + max(M,N)) floats */
 } cclip_gemm_desc;
 int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream);
 

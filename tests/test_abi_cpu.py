@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 19, names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/cclip_hip.h but not exported"
-    assert lib.cclip_abi_version() == 2
+    assert lib.cclip_abi_version() == 3
 
 
 def test_no_torch_types_in_abi():

@@ -244,27 +244,31 @@ def test_gemm_skinny_decode_shapes(M, N, K, kind, dt):
 # ---- bias gradient fused into the weight-gradient GEMM (row sums of A over K) ------------------------------------------
 @pytest.mark.parametrize("cfg,split", [(1, 1), (2, 1), (1, 8), (2, 5), (0, 0)])
 @pytest.mark.parametrize("n_out,k_in,tokens", [(768, 256, 5000), (2304, 768, 3136), (200, 136, 1000)])
-def test_wgrad_with_fused_bias_gradient(n_out, k_in, tokens, cfg, split):
+@pytest.mark.parametrize("conv1d", [False, True])
+def test_wgrad_with_fused_bias_gradient(n_out, k_in, tokens, cfg, split, conv1d):
+    """conv1d: GPT-2's [in, out] weight layout - the gradient is x^T dy and dy is the B operand (colsum_of_b)."""
     o = _ops()
     g = torch.Generator(device="cuda").manual_seed(n_out + k_in + tokens)
     dy = torch.randn(tokens, n_out, device="cuda", generator=g).bfloat16()
     x = torch.randn(tokens, k_in, device="cuda", generator=g).bfloat16()
-    ref_w = dy.float().t() @ x.float()
+    ref_w = x.float().t() @ dy.float() if conv1d else dy.float().t() @ x.float()
     ref_b = dy.float().sum(0)
+    A_, B_ = (x, dy) if conv1d else (dy, x)
+    M_, N_ = ref_w.shape
     for accumulate in (False, True):
-        gw = torch.randn(n_out, k_in, device="cuda", generator=g)
+        gw = torch.randn(M_, N_, device="cuda", generator=g)
         gb = torch.randn(n_out, device="cuda", generator=g)
         gw0, gb0 = gw.clone(), gb.clone()
         kw = {}
         if cfg == 0:        # the way the model calls it: autotuned (tile, split) candidates + scratch callback
             from cclip_hip.stack import Scratch, wgrad_candidates
-            kw = dict(split_candidates=wgrad_candidates(n_out, k_in, tokens), scratch=Scratch(torch.device("cuda")).floats)
+            kw = dict(split_candidates=wgrad_candidates(M_, N_, tokens), scratch=Scratch(torch.device("cuda")).floats)
         elif split > 1:
-            kw = dict(tile_config=cfg, split_k=split, split_ws=torch.empty(split * n_out * (k_in + 1), device="cuda"))
+            kw = dict(tile_config=cfg, split_k=split, split_ws=torch.empty(split * (M_ * N_ + max(M_, N_)), device="cuda"))
         else:
             kw = dict(tile_config=cfg)
-        o.gemm_bf16(dy, x, a_kcontig=False, b_kcontig=False, residual=gw if accumulate else None, out_f32=gw,
-                    colsum_out=gb, colsum_accumulate=accumulate, **kw)
+        o.gemm_bf16(A_, B_, a_kcontig=False, b_kcontig=False, residual=gw if accumulate else None, out_f32=gw,
+                    colsum_out=gb, colsum_accumulate=accumulate, colsum_of_b=conv1d, **kw)
         _report("fused wgrad", gw, ref_w + (gw0 if accumulate else 0), 2e-3)
         want_b = ref_b + (gb0 if accumulate else 0)
         assert (gb - want_b).abs().max() <= 2e-3 * want_b.abs().max(), (gb - want_b).abs().max()
