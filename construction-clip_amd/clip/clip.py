@@ -61,6 +61,14 @@ def _transform(n_px: int) -> _Transform:
     return _Transform(n_px)
 
 
+def _load_dtype() -> torch.dtype:
+    """MFMA operand type of a model returned by clip.load: fp16, as openai/CLIP's own clip.load gives on a CUDA device (its
+    build_model() converts the weights to fp16) and the mode in which this build meets the <= 1e-3 parity target with
+    bit-exact arg-max; masters, residual stream, LayerNorm statistics and the head stay fp32 either way.
+    CCLIP_COMPUTE_DTYPE=bf16 (or model.bfloat16()) selects bf16 operands - the training benchmark's choice (wider range)."""
+    return torch.bfloat16 if os.environ.get("CCLIP_COMPUTE_DTYPE", "fp16").lower() in ("bf16", "bfloat16") else torch.float16
+
+
 def load(name: str, device: Union[str, torch.device] = "cuda" if torch.cuda.is_available() else "cpu",
          jit: bool = False, download_root: str = None):
     """Returns (model, preprocess).  `name` is a model name from available_models() or a path to a
@@ -85,11 +93,11 @@ def load(name: str, device: Union[str, torch.device] = "cuda" if torch.cuda.is_a
     if sd is not None:
         if "state_dict" in sd and isinstance(sd["state_dict"], dict):
             sd = sd["state_dict"]
-        model = build_model(sd)
+        model = build_model(sd, _load_dtype())
     else:
         warnings.warn(f"clip.load({name!r}): no local checkpoint and no network - using seeded synthetic weights "
                       "(seed 567); load a state_dict to get a trained model")
-        model = CLIP(MODELS[name])
+        model = CLIP(MODELS[name], _load_dtype())
         model.load_state_dict(init_state_dict(MODELS[name], 567))
         model.eval()
     model = model.to(device)
