@@ -346,6 +346,11 @@ def main():
             traffic = round((gf["fetch_mb_per_launch_corrected"] + gf["write_mb_per_launch"]) * 1e6)
             traffic_src = "profiles/r01_train_bs1024_hbm_traffic_pmc.json"
         roof = gemm_roofline(ev, nprof, traffic, traffic_src)
+        mp = os.path.join(ROOT, "profiles", "r01_train_bs1024_mfma_busy_pmc.json")
+        if os.path.exists(mp) and traffic is not None:
+            # matrix-pipe busy fraction of the GEMM family from the committed PMC pass of the same command (clock-independent)
+            roof["mfma_busy"] = json.load(open(mp))["gemm_family_mfma_busy"]
+            roof["mfma_busy_source"] = "profiles/r01_train_bs1024_mfma_busy_pmc.json"
     if world > 1:
         dist.barrier()
 
