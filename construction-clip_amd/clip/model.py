@@ -232,6 +232,10 @@ class CLIP(nn.Module):
         B, T, D, P = image.shape[0], geo.vision_tokens, geo.vision_width, geo.vision_patch_size
         if tuple(image.shape[1:]) != (3, geo.image_resolution, geo.image_resolution):
             raise RuntimeError(f"encode_image: expected [N,3,{geo.image_resolution},{geo.image_resolution}], got {tuple(image.shape)}")
+        if B == 0:                                   # empty batch (the reference returns an empty [0, embed] tensor)
+            if train:
+                raise RuntimeError("encode_image: empty batch in a training step")
+            return torch.empty(0, geo.embed_dim, device=dev, dtype=torch.float32), None
         M = B * T
         img = image.detach().to(torch.float32).contiguous()
         KP = 3 * P * P
@@ -316,6 +320,10 @@ class CLIP(nn.Module):
         if text.dim() != 2 or text.shape[1] != geo.context_length:
             raise RuntimeError(f"encode_text: expected [N,{geo.context_length}] token ids, got {tuple(text.shape)}")
         B, D = text.shape[0], geo.transformer_width
+        if B == 0:
+            if train:
+                raise RuntimeError("encode_text: empty batch in a training step")
+            return torch.empty(0, geo.embed_dim, device=dev, dtype=torch.float32), None
         eot = text.detach().argmax(dim=-1)
         # The tower is causal and only the EOT row is pooled: positions after the LAST EOT of the batch influence nothing.
         # trim_text_padding runs the tower on [0, max EOT] only (real captions are ~10-30 tokens of the 77): identical
@@ -414,6 +422,10 @@ class CLIP(nn.Module):
         return fi, ft
 
     def forward(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if image.shape[0] == 0 or text.shape[0] == 0:      # nothing to score: empty logits of the right shape
+            _require_cuda(image, "forward")
+            li = torch.empty(image.shape[0], text.shape[0], device=image.device, dtype=torch.float32)
+            return li, li.t()
         fi, ft = self.encode_image_text(image, text)
         logits_per_image = _Logits.apply(fi, ft, self.logit_scale)
         return logits_per_image, logits_per_image.t()

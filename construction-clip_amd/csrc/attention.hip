@@ -50,37 +50,62 @@ __device__ __forceinline__ bf16x8 frag_row(const char* img, int row, int chunk) 
   return *(const bf16x8*)(img + at_off(row, chunk));
 }
 
-// stage rows [0, rows_total) of a [T][64] head slice into LDS (zero rows >= T)
-__device__ __forceinline__ void stage_head(const bf16* g, long ld, long row0, int T, int rows_total, char* img, int tid) {
-  for (int idx = tid; idx < rows_total * 8; idx += 256) {
-    const int row = idx >> 3, c = idx & 7;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (row < T) val = *(const uint4*)(g + (row0 + row) * ld + c * 8);
-    *(uint4*)(img + at_off(row, c)) = val;
+// Staging of a [T][64] head slice into LDS in two halves: head_load issues every 16-byte global load of the slice (IT per
+// thread, rows clamped so that no load is predicated) and head_store writes them to the swizzled image, zeroing rows >= T.
+// All loads of all operands go out before the first wait: a predicated load -> wait -> ds_write loop costs one HBM round
+// trip per iteration (8-10 serial round trips were most of a T=50 workgroup's life, rocprofv3 + ISA).
+template <int IT>
+__device__ __forceinline__ void head_load(const bf16* g, long ld, long row0, int T, uint4 (&r)[IT], int tid) {
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = tid + 256 * it, row = idx >> 3, c = idx & 7;
+    r[it] = *(const uint4*)(g + (row0 + (row < T ? row : T - 1)) * ld + c * 8);
+  }
+}
+template <int IT>
+__device__ __forceinline__ void head_store(char* img, int T, int rows_total, const uint4 (&r)[IT], int tid) {
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = tid + 256 * it, row = idx >> 3, c = idx & 7;
+    if (row < rows_total) *(uint4*)(img + at_off(row, c)) = row < T ? r[it] : make_uint4(0, 0, 0, 0);
   }
 }
 
 template <int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NKS = (NKT + 1) / 2, TP = 16 * NKT, TP32 = 32 * NKS;
-  __shared__ __attribute__((aligned(16))) char smem[(TP + TP32) * 128];
+  __shared__ __attribute__((aligned(16))) char smem[(TP + TP32) * 128 + TP32 * 4];
   char* Ks = smem;
   char* Vs = smem + TP * 128;
+  float* keep_s = (float*)(smem + (TP + TP32) * 128);      // 1 = key exists and is not padding-masked
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int T = a.T;
   const long row0 = (long)b * T;
-  stage_head(a.k + h * 64, a.ldk, row0, T, TP, Ks, tid);
-  stage_head(a.v + h * 64, a.ldv, row0, T, TP32, Vs, tid);
-  __syncthreads();
   const int nqt = (T + 15) >> 4;
+  bf16x8 qn0, qn1;                                         // this wave's first query tile rides along with K and V
+  {
+    uint4 rk[NKS], rv[NKS];
+    head_load<NKS>(a.k + h * 64, a.ldk, row0, T, rk, tid);
+    head_load<NKS>(a.v + h * 64, a.ldv, row0, T, rv, tid);
+    const int qi = 16 * wave + li;
+    const bf16* qp = a.q + (row0 + (qi < T ? qi : T - 1)) * a.ldq + h * 64 + 8 * g;
+    qn0 = *(const bf16x8*)qp; qn1 = *(const bf16x8*)(qp + 32);
+    if (tid < TP32) keep_s[tid] = (tid < T && (!a.keep || a.keep[row0 + tid] != 0.f)) ? 1.f : 0.f;
+    head_store<NKS>(Ks, T, TP, rk, tid);
+    head_store<NKS>(Vs, T, TP32, rv, tid);
+  }
+  __syncthreads();
   const float NEG = -__builtin_inff();
   for (int qt = wave; qt < nqt; qt += 4) {
     const int qi = 16 * qt + li;
-    const int qrow = qi < T ? qi : T - 1;
-    const bf16* qp = a.q + (row0 + qrow) * a.ldq + h * 64 + 8 * g;
-    const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+    const bf16x8 qf0 = qn0, qf1 = qn1;
+    if (qt + 4 < nqt) {                                    // T > 64 only: the next tile's rows load under this tile's math
+      const int qx = qi + 64;
+      const bf16* qp = a.q + (row0 + (qx < T ? qx : T - 1)) * a.ldq + h * 64 + 8 * g;
+      qn0 = *(const bf16x8*)qp; qn1 = *(const bf16x8*)(qp + 32);
+    }
     int ktmax = NKT - 1;
     if (a.causal && qt < ktmax) ktmax = qt;
     f32x4 s[NKT];
@@ -94,16 +119,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     }
     float m = NEG;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      const float4 kp4 = *(const float4*)(keep_s + 16 * kt + 4 * g);
+      const float kp[4] = {kp4.x, kp4.y, kp4.z, kp4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kt + 4 * g + r;
-        bool ok = kt <= ktmax && key < T && (!a.causal || key <= qi);
-        if (ok && a.keep) ok = a.keep[row0 + key] != 0.f;
+        const bool ok = kt <= ktmax && kp[r] != 0.f && (!a.causal || key <= qi);
         const float val = ok ? s[kt][r] * a.scale : NEG;
         s[kt][r] = val;
         m = fmaxf(m, val);
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float msafe = m == NEG ? 0.f : m;
@@ -153,7 +180,7 @@ template <int NKT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   constexpr int NKS = (NKT + 1) / 2, TP32 = 32 * NKS;
   constexpr int DS_LD = 2 * TP32 + 16;                     // padded dS row stride (bytes)
-  __shared__ __attribute__((aligned(16))) char smem[4 * TP32 * 128 + TP32 * DS_LD + 2 * TP32 * 4];
+  __shared__ __attribute__((aligned(16))) char smem[4 * TP32 * 128 + TP32 * DS_LD + 3 * TP32 * 4];
   char* Qs = smem;
   char* Ks = Qs + TP32 * 128;
   char* Vs = Ks + TP32 * 128;
@@ -161,34 +188,42 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   char* dSs = Os + TP32 * 128;                             // [q][key] bf16
   float* lse_s = (float*)(dSs + TP32 * DS_LD);
   float* del_s = lse_s + TP32;
+  float* keep_s = del_s + TP32;                            // 1 = key exists and is not padding-masked
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int T = a.T;
   const long row0 = (long)b * T;
-  stage_head(a.q + h * 64, a.ldq, row0, T, TP32, Qs, tid);
-  stage_head(a.k + h * 64, a.ldk, row0, T, TP32, Ks, tid);
-  stage_head(a.v + h * 64, a.ldv, row0, T, TP32, Vs, tid);
-  stage_head(a.dout + h * 64, a.lddo, row0, T, TP32, Os, tid);
-  // zero dS (tiles skipped by the causal structure are read as zeros), lse, delta = rowsum(dO * O)
-  for (int i = tid; i < TP32 * DS_LD / 16; i += 256) *(uint4*)(dSs + i * 16) = make_uint4(0, 0, 0, 0);
-  for (int rr = tid >> 2; rr < TP32; rr += 64) {
-    const int part = tid & 3;
-    float acc = 0.f;
-    if (rr < T) {
-      const bf16* op = a.o + (row0 + rr) * a.ldo + h * 64 + part * 16;
-      const bf16* dp = a.dout + (row0 + rr) * a.lddo + h * 64 + part * 16;
-      const bf16x8 o0 = *(const bf16x8*)op, o1 = *(const bf16x8*)(op + 8);
-      const bf16x8 d0 = *(const bf16x8*)dp, d1 = *(const bf16x8*)(dp + 8);
+  {
+    uint4 rq[NKS], rk[NKS], rv[NKS], rdo[NKS], ro[NKS];    // TP32 * 8 chunks = 256 * NKS: NKS per thread and operand
+    head_load<NKS>(a.q + h * 64, a.ldq, row0, T, rq, tid);
+    head_load<NKS>(a.k + h * 64, a.ldk, row0, T, rk, tid);
+    head_load<NKS>(a.v + h * 64, a.ldv, row0, T, rv, tid);
+    head_load<NKS>(a.dout + h * 64, a.lddo, row0, T, rdo, tid);
+    head_load<NKS>(a.o + h * 64, a.ldo, row0, T, ro, tid);
+    float lse_r = 1e30f;                                   // rows >= T: P = exp(s - 1e30) = 0
+    if (tid < T) lse_r = a.lse[((long)b * a.H + h) * T + tid];
+    const float keep_r = (tid < T && (!a.keep || a.keep[row0 + tid] != 0.f)) ? 1.f : 0.f;
+    // zero dS (tiles skipped by the causal structure are read as zeros) while the loads fly
+    for (int i = tid; i < TP32 * DS_LD / 16; i += 256) *(uint4*)(dSs + i * 16) = make_uint4(0, 0, 0, 0);
+    head_store<NKS>(Qs, T, TP32, rq, tid);
+    head_store<NKS>(Ks, T, TP32, rk, tid);
+    head_store<NKS>(Vs, T, TP32, rv, tid);
+    head_store<NKS>(Os, T, TP32, rdo, tid);
+    // delta = rowsum(dO * O): the 8 threads that hold a row's chunks each dot their 8 elements
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc += (float)o0[j] * (float)d0[j] + (float)o1[j] * (float)d1[j];
+    for (int it = 0; it < NKS; ++it) {
+      const int row = (tid >> 3) + 32 * it;
+      const bf16x8 ov = __builtin_bit_cast(bf16x8, ro[it]), dv = __builtin_bit_cast(bf16x8, rdo[it]);
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += (float)ov[j] * (float)dv[j];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      if ((tid & 7) == 0) del_s[row] = row < T ? acc : 0.f;
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) {
-      del_s[rr] = acc;
-      lse_s[rr] = rr < T ? a.lse[((long)b * a.H + h) * T + rr] : 1e30f;
-    }
+    if (tid < TP32) { lse_s[tid] = lse_r; keep_s[tid] = keep_r; }
   }
   __syncthreads();
   const int nkt = (T + 15) >> 4;                           // live key / query tiles
@@ -200,8 +235,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dvT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int key = 16 * kt + li;
-    bool key_ok = key < T;
-    if (key_ok && a.keep) key_ok = a.keep[row0 + key] != 0.f;
+    const bool key_ok = keep_s[key] != 0.f;
     const bf16x8 kf0 = frag_row(Ks, key, g), kf1 = frag_row(Ks, key, 4 + g);
     const bf16x8 vf0 = frag_row(Vs, key, g), vf1 = frag_row(Vs, key, 4 + g);
     for (int ss = 0; ss < NKS; ++ss) {

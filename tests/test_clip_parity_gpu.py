@@ -293,3 +293,21 @@ def test_trim_text_padding_changes_nothing_but_the_row_count(dtype):
     for n in outs[0][2]:
         assert rel(outs[1][2][n], outs[0][2][n]) < 2e-2, n
     assert torch.equal(outs[1][2]["positional_embedding"][8:], torch.zeros_like(outs[1][2]["positional_embedding"][8:]))
+
+
+def test_empty_and_single_row_batches():
+    """Edge cases of the reference's call sites: an empty image folder (CLIP/predict.py batches whatever it finds) gives
+    empty [0, embed] features, and a batch of one matches row 0 of the same inputs encoded in a larger batch."""
+    g, model, img, txt = _setup("clip_test_small.pt")
+    E = model.geo.embed_dim
+    with torch.no_grad():
+        e_i, e_t = model.encode_image(img[:0]), model.encode_text(txt[:0])
+        assert e_i.shape == (0, E) and e_t.shape == (0, E)
+        li, lt = model(img[:0], txt)
+        assert li.shape == (0, txt.shape[0]) and lt.shape == (txt.shape[0], 0)
+        one_i, one_t = model.encode_image(img[:1]), model.encode_text(txt[:1])
+        all_i, all_t = model.encode_image(img), model.encode_text(txt)
+    assert rel(one_i, all_i[:1]) < 2e-3 and rel(one_t, all_t[:1]) < 2e-3
+    model.train()
+    with pytest.raises(RuntimeError):
+        model.encode_image(img[:0])
