@@ -5,7 +5,8 @@
 // position's logits - O(S^2) work per caption.  With a KV cache the step is one token wide; this kernel is its
 // softmax(q K^T * scale) V.  The new token attends to every cached position (its own included), so there is no mask.
 // Work per step is tiny (beams x heads workgroups, S <= 1024 keys) and bound by reading the cache once:
-// one wave per (sequence, head), fp32 math, K rows read as 128-byte rows per lane group, V rows coalesced.
+// one wave per (sequence, head), fp32 math, K rows read as 128-byte rows per lane, V rows as 16-byte chunks with four
+// loads in flight per lane.
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
@@ -47,9 +48,37 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16* __restrict_
   }
   l = wave_sum(l);
   __syncthreads();
-  float acc = 0.f;                                   // lane = output dimension
-  for (int key = 0; key < S; ++key) acc += p[key] * (float)vb[(long)key * ld_pos + lane];
-  out[(long)b * ldo + h * 64 + lane] = (bf16)(acc / l);
+  // O = P V: lane (kg, c) owns keys kg, kg + 8, ... and the 8 output dimensions 8c..8c+7; four 16-byte V loads are in
+  // flight per trip (a one-key-per-iteration loop is S serial memory round trips), then the 8 key groups are summed
+  const int c = lane & 7, kg = lane >> 3;
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+  for (int k0 = 0; k0 < S; k0 += 32) {
+    bf16x8 vv[4];
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = k0 + 8 * u + kg;
+      vv[u] = *(const bf16x8*)(vb + (long)(key < S ? key : S - 1) * ld_pos + 8 * c);
+      w[u] = key < S ? p[key] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += w[u] * (float)vv[u][j];
+  }
+  const float inv = 1.0f / l;
+  bf16x8 ov;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float t = o[j];
+    t += __shfl_xor(t, 8, 64);
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    ov[j] = (bf16)(t * inv);
+  }
+  if (kg == 0) *(bf16x8*)(out + (long)b * ldo + h * 64 + 8 * c) = ov;
 }
 
 }  // namespace CCLIP_NS
@@ -59,7 +88,7 @@ extern "C" int CCLIP_FN(cclip_attention_decode)(const void* q, int64_t ldq, cons
                                                int64_t ld_seq, void* out, int64_t ldo, int32_t B, int32_t H, int32_t S,
                                                float scale, hipStream_t stream) {
   if (!q || !kcache || !vcache || !out || B <= 0 || H <= 0 || S <= 0 || S > DEC_MAXS) return CCLIP_ERR_ARG;
-  if ((ld_pos & 7) || (ld_seq & 7) || (((uintptr_t)kcache | (uintptr_t)vcache) & 15)) return CCLIP_ERR_ARG;
+  if ((ld_pos & 7) || (ld_seq & 7) || (ldo & 7) || (((uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)out) & 15)) return CCLIP_ERR_ARG;
   hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(64), 0, stream, (const bf16*)q, (long)ldq, (const bf16*)kcache,
                      (const bf16*)vcache, (long)ld_pos, (long)ld_seq, (bf16*)out, (long)ldo, H, S, scale);
   return cclip_launch_status();

@@ -44,24 +44,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ cs_ws, float* __restrict__ cs_dst, int cs_acc, int cs_len) {
   if (cs_dst) {                                            // fused bias gradient: sum the per-split row sums
     for (long m = blockIdx.x * 256L + threadIdx.x; m < cs_len; m += (long)gridDim.x * 256L) {
+      const float prev = cs_acc ? cs_dst[m] : 0.f;
       float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += cs_ws[(long)z * cs_len + m];
-      cs_dst[m] = (cs_acc ? cs_dst[m] : 0.f) + s;
+      int z = 0;
+      for (; z + 4 <= splits; z += 4) {                    // loads first, adds in split order (see below)
+        const float t0 = cs_ws[(long)(z + 0) * cs_len + m], t1 = cs_ws[(long)(z + 1) * cs_len + m];
+        const float t2 = cs_ws[(long)(z + 2) * cs_len + m], t3 = cs_ws[(long)(z + 3) * cs_len + m];
+        s += t0; s += t1; s += t2; s += t3;
+      }
+      for (; z < splits; ++z) s += cs_ws[(long)z * cs_len + m];
+      cs_dst[m] = prev + s;
     }
   }
   const long total = (long)M * N / 4;
+  const long zs = (long)M * N;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    // every partial (and the residual) is requested before the first add: a load -> wait -> add loop is `splits` serial
+    // HBM round trips per thread, which was most of this kernel's 13 us.  Same summation order as the plain loop.
+    const long m = (i * 4) / N, n = (i * 4) % N;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (residual) r = *(const float4*)(residual + m * ldr + n);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < splits; ++z) {
-      const float4 t = *(const float4*)(ws + ((long)z * M * N) + i * 4);
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    const float* wp = ws + i * 4;
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+      const float4 t0 = *(const float4*)(wp + (z + 0) * zs), t1 = *(const float4*)(wp + (z + 1) * zs);
+      const float4 t2 = *(const float4*)(wp + (z + 2) * zs), t3 = *(const float4*)(wp + (z + 3) * zs);
+      s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+      s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+      s.x += t2.x; s.y += t2.y; s.z += t2.z; s.w += t2.w;
+      s.x += t3.x; s.y += t3.y; s.z += t3.z; s.w += t3.w;
+    }
+    if (z + 2 <= splits) {
+      const float4 t0 = *(const float4*)(wp + (z + 0) * zs), t1 = *(const float4*)(wp + (z + 1) * zs);
+      s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+      s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+      z += 2;
+    }
+    if (z < splits) {
+      const float4 t0 = *(const float4*)(wp + z * zs);
+      s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
     }
     s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
-    const long m = (i * 4) / N, n = (i * 4) % N;
-    if (residual) {
-      const float4 r = *(const float4*)(residual + m * ldr + n);
-      s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
-    }
+    s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
     if (out_f32) *(float4*)(out_f32 + m * ldc + n) = s;
     if (out_bf16) {
       bf16x4 o = {(bf16)s.x, (bf16)s.y, (bf16)s.z, (bf16)s.w};
@@ -133,7 +158,7 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   if (st != CCLIP_OK) return st;
   if (splits > 1) {
     long total = (long)d->M * d->N / 4;
-    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((total + 255) / 256); if (blocks > (1 << 20)) blocks = 1 << 20;   // one float4 per thread
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d->split_ws, splits, d->M, d->N,
                        d->alpha, d->residual, d->ldr, d->out_f32, (bf16*)d->out_bf16, d->ldc, a.colsum_ws, a.colsum_dst, a.colsum_acc, a.colsum_b ? d->N : d->M);
     st = cclip_launch_status();

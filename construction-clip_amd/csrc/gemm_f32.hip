@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
   if (alpha_log_dev) alpha *= __expf(*alpha_log_dev);
   // D[i = 4g + r][j = li]: i <-> n (from the B-side operand), j <-> m
+  // beta != 0 (gradient accumulation): all 16 previous values are requested first, clamped in-bounds so that no load is
+  // predicated - a per-element load -> fma -> store chain is 16 serial memory round trips
+  float prev[2][2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        prev[mt][nt][r] = 0.f;
+        if (beta != 0.f) {
+          const int m = min(bm0 + wm0 + 16 * mt + li, M - 1), n = min(bn0 + wn0 + 16 * nt + 4 * g + r, N - 1);
+          prev[mt][nt][r] = C[(long)m * ldc + n];
+        }
+      }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int m = bm0 + wm0 + 16 * mt + li;
@@ -89,12 +104,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + r;
-        if (n < N) {
-          float* cp = C + (long)m * ldc + n;
-          float v = alpha * acc[mt][nt][r];
-          if (beta != 0.f) v += beta * *cp;
-          *cp = v;
-        }
+        if (n < N) C[(long)m * ldc + n] = alpha * acc[mt][nt][r] + beta * prev[mt][nt][r];
       }
     }
   }

@@ -143,7 +143,8 @@ int cclip_attention_small_bwd(const cclip_attn_desc* d, hipStream_t stream);
  * KV-cached replacement for the reference's generate_beam / generate2 loops, which re-run GPT-2 on the whole
  * growing sequence every step (CLIP_prefix_caption/test.py:381,468; application.py:180).  q/out: [B, >= H*64]
  * 16-bit; kcache/vcache: position s of sequence b at element offset b*ld_seq + s*ld_pos, head h at +h*64;
- * S = number of cached positions INCLUDING the new token's own (<= 2048).  No mask (the newest token sees all). */
+ * S = number of cached positions INCLUDING the new token's own (<= 2048).  No mask (the newest token sees all).
+ * ld_pos, ld_seq, ldo multiples of 8 elements; kcache, vcache, out 16-byte aligned (CCLIP_ERR_ARG otherwise). */
 int cclip_attention_decode(const void* q, int64_t ldq, const void* kcache, const void* vcache, int64_t ld_pos,
                            int64_t ld_seq, void* out, int64_t ldo, int32_t B, int32_t H, int32_t S, float scale,
                            hipStream_t stream);
