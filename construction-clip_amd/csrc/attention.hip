@@ -471,35 +471,49 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const AttnArgs a, in
 // is recomputed per staged query block.  Same operand roles as attn_bwd_kernel: query on accumulator rows, so P and dS
 // are B operands of dV^T = dO^T P and dK^T = Q^T dS without data movement; dS crosses LDS once for dQ^T = K^T dS^T.
 //
-// stage 64 rows [r0, r0+64) of a [T][64] head slice (zero rows >= T) - one 16-byte chunk per thread per 32 rows
-__device__ __forceinline__ void stage_block64(const bf16* g, long ld, long row0, int r0, int T, char* img, int tid) {
+// Staging of 64 rows [r0, r0+64) of a [T][64] head slice, split as in the short kernels: blk_load requests the thread's
+// two 16-byte chunks (rows clamped: no predicated load), blk_store writes them to the swizzled image (zero rows >= T).
+// Between the two a kernel keeps the NEXT block's chunks in registers while the current block is multiplied.
+__device__ __forceinline__ void blk_load(const bf16* g, long ld, long row0, int r0, int T, uint4 (&r)[2], int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int row = (tid >> 3) + 32 * i, c = tid & 7;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (r0 + row < T) val = *(const uint4*)(g + (row0 + r0 + row) * ld + c * 8);
-    *(uint4*)(img + at_off(row, c)) = val;
+    const int row = r0 + (tid >> 3) + 32 * i;
+    r[i] = *(const uint4*)(g + (row0 + (row < T ? row : T - 1)) * ld + (tid & 7) * 8);
   }
 }
-
-// lse and delta = rowsum(dO * O) of query rows [q0, q0 + 64) into LDS (rows >= T: lse = +big so that P = 0)
-__device__ __forceinline__ void stage_lse_delta64(const AttnArgs& a, long row0, int b, int h, int q0, float* lse_s, float* del_s, int tid) {
-  const int rr = tid >> 2, part = tid & 3, q = q0 + rr;
-  float acc = 0.f;
-  if (q < a.T) {
-    const bf16* op = a.o + (row0 + q) * a.ldo + h * 64 + part * 16;
-    const bf16* dp = a.dout + (row0 + q) * a.lddo + h * 64 + part * 16;
-    const bf16x8 o0 = *(const bf16x8*)op, o1 = *(const bf16x8*)(op + 8);
-    const bf16x8 d0 = *(const bf16x8*)dp, d1 = *(const bf16x8*)(dp + 8);
+__device__ __forceinline__ void blk_store(char* img, int r0, int T, const uint4 (&r)[2], int tid) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc += (float)o0[j] * (float)d0[j] + (float)o1[j] * (float)d1[j];
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    *(uint4*)(img + at_off(row, tid & 7)) = r0 + row < T ? r[i] : make_uint4(0, 0, 0, 0);
   }
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  if (part == 0) {
-    del_s[rr] = acc;
-    lse_s[rr] = q < a.T ? a.lse[((long)b * a.H + h) * a.T + q] : 1e30f;
+}
+// one query block's Q, dO, O chunks and log-sum-exp in registers
+struct QBlockRegs { uint4 q[2], d[2], o[2]; float lse; };
+__device__ __forceinline__ void qblk_load(const AttnArgs& a, long row0, int b, int h, int q0, QBlockRegs& r, int tid) {
+  blk_load(a.q + h * 64, a.ldq, row0, q0, a.T, r.q, tid);
+  blk_load(a.dout + h * 64, a.lddo, row0, q0, a.T, r.d, tid);
+  blk_load(a.o + h * 64, a.ldo, row0, q0, a.T, r.o, tid);
+  r.lse = 1e30f;                                          // rows >= T: P = exp(s - 1e30) = 0
+  if (tid < 64 && q0 + tid < a.T) r.lse = a.lse[((long)b * a.H + h) * a.T + q0 + tid];
+}
+// ... into LDS: Q and dO images, lse, and delta = rowsum(dO * O) from the chunks the 8 threads of a row hold
+__device__ __forceinline__ void qblk_store(const QBlockRegs& r, int q0, int T, char* Qs, char* Os, float* lse_s, float* del_s, int tid) {
+  blk_store(Qs, q0, T, r.q, tid);
+  blk_store(Os, q0, T, r.d, tid);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    const bf16x8 ov = __builtin_bit_cast(bf16x8, r.o[i]), dv = __builtin_bit_cast(bf16x8, r.d[i]);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)ov[j] * (float)dv[j];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if ((tid & 7) == 0) del_s[row] = q0 + row < T ? acc : 0.f;
   }
+  if (tid < 64) lse_s[tid] = r.lse;
 }
 
 // dK, dV of one 64-key block: wave w owns key tile w; all query blocks stream through LDS
@@ -517,8 +531,17 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const AttnArgs a
   const int b = bh / a.H, h = bh % a.H;
   const int T = a.T;
   const long row0 = (long)b * T;
-  stage_block64(a.k + h * 64, a.ldk, row0, 64 * kb, T, Ks, tid);
-  stage_block64(a.v + h * 64, a.ldv, row0, 64 * kb, T, Vs, tid);
+  const int nqb = (T + 63) >> 6;
+  const int qb0 = a.causal ? kb : 0;                      // causal: query blocks above the diagonal see none of these keys
+  QBlockRegs qr;
+  {
+    uint4 rk[2], rv[2];
+    blk_load(a.k + h * 64, a.ldk, row0, 64 * kb, T, rk, tid);
+    blk_load(a.v + h * 64, a.ldv, row0, 64 * kb, T, rv, tid);
+    qblk_load(a, row0, b, h, 64 * qb0, qr, tid);          // the first query block rides along
+    blk_store(Ks, 64 * kb, T, rk, tid);
+    blk_store(Vs, 64 * kb, T, rv, tid);
+  }
   __syncthreads();
   const int keyl = 16 * wave + li, key = 64 * kb + keyl;
   bool key_ok = key < T;
@@ -528,13 +551,11 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const AttnArgs a
   f32x4 dvT[4], dkT[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dvT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  const int nqb = (T + 63) >> 6;
-  for (int qb = a.causal ? kb : 0; qb < nqb; ++qb) {      // causal: query blocks above the diagonal see none of these keys
+  for (int qb = qb0; qb < nqb; ++qb) {
+    __syncthreads();                                      // the previous block's readers are done
+    qblk_store(qr, 64 * qb, T, Qs, Os, lse_s, del_s, tid);
     __syncthreads();
-    stage_block64(a.q + h * 64, a.ldq, row0, 64 * qb, T, Qs, tid);
-    stage_block64(a.dout + h * 64, a.lddo, row0, 64 * qb, T, Os, tid);
-    stage_lse_delta64(a, row0, b, h, 64 * qb, lse_s, del_s, tid);
-    __syncthreads();
+    if (qb + 1 < nqb) qblk_load(a, row0, b, h, 64 * (qb + 1), qr, tid);   // in flight during this block's MFMAs
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       bf16x8 pf, dsf;
@@ -596,9 +617,14 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const AttnArgs a,
   const int b = bh / a.H, h = bh % a.H;
   const int T = a.T;
   const long row0 = (long)b * T;
-  stage_block64(a.q + h * 64, a.ldq, row0, 64 * qb, T, Qs, tid);
-  stage_block64(a.dout + h * 64, a.lddo, row0, 64 * qb, T, Os, tid);
-  stage_lse_delta64(a, row0, b, h, 64 * qb, lse_s, del_s, tid);
+  uint4 rk[2], rv[2];
+  {
+    QBlockRegs qr;
+    qblk_load(a, row0, b, h, 64 * qb, qr, tid);
+    blk_load(a.k + h * 64, a.ldk, row0, 0, T, rk, tid);   // the first key block rides along
+    blk_load(a.v + h * 64, a.ldv, row0, 0, T, rv, tid);
+    qblk_store(qr, 64 * qb, T, Qs, Os, lse_s, del_s, tid);
+  }
   f32x4 dqT[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dqT[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -607,9 +633,13 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const AttnArgs a,
   const int qrow = 16 * wave + li;                        // this lane's query row as an A-operand row (S, dP)
   for (int kb = 0; kb < nkb; ++kb) {
     __syncthreads();                                      // previous block's dS / K readers are done
-    stage_block64(a.k + h * 64, a.ldk, row0, 64 * kb, T, Ks, tid);
-    stage_block64(a.v + h * 64, a.ldv, row0, 64 * kb, T, Vs, tid);
+    blk_store(Ks, 64 * kb, T, rk, tid);
+    blk_store(Vs, 64 * kb, T, rv, tid);
     __syncthreads();
+    if (kb + 1 < nkb) {                                   // in flight during this block's MFMAs
+      blk_load(a.k + h * 64, a.ldk, row0, 64 * (kb + 1), T, rk, tid);
+      blk_load(a.v + h * 64, a.ldv, row0, 64 * (kb + 1), T, rv, tid);
+    }
     const float4 ls = *(const float4*)(lse_s + 16 * wave + 4 * g);
     const float4 de = *(const float4*)(del_s + 16 * wave + 4 * g);
     const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};

@@ -21,20 +21,38 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16* __restrict_
   __shared__ float qs[64];
   const int lane = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  qs[lane] = (float)q[(long)b * ldq + h * 64 + lane];
-  __syncthreads();
   const bf16* kb = kc + (long)b * ld_seq + h * 64;
   const bf16* vb = vc + (long)b * ld_seq + h * 64;
+  bf16x8 kv[8];                                      // lane's first key row, 128 bytes in 8 loads that go out together
+  {
+    const bf16* kr = kb + (long)(lane < S ? lane : S - 1) * ld_pos;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kv[c] = *(const bf16x8*)(kr + 8 * c);
+  }
+  // ... and the first 32 V rows of the PV phase (lane (kg, c): keys kg + 8u, dimensions 8c..8c+7), so that the
+  // softmax runs under their latency
+  const int c = lane & 7, kg = lane >> 3;
+  bf16x8 vv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int key = 8 * u + kg;
+    vv[u] = *(const bf16x8*)(vb + (long)(key < S ? key : S - 1) * ld_pos + 8 * c);
+  }
+  const bf16 qv = q[(long)b * ldq + h * 64 + lane];
+  qs[lane] = (float)qv;
+  __syncthreads();
   float m = -__builtin_inff();
   for (int key = lane; key < S; key += 64) {
-    const bf16* kr = kb + (long)key * ld_pos;
+    if (key != lane) {
+      const bf16* kr = kb + (long)key * ld_pos;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) kv[cc] = *(const bf16x8*)(kr + 8 * cc);
+    }
     float acc = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const bf16x8 kv = *(const bf16x8*)(kr + 8 * c);
+    for (int cc = 0; cc < 8; ++cc)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc += qs[8 * c + j] * (float)kv[j];
-    }
+      for (int j = 0; j < 8; ++j) acc += qs[8 * cc + j] * (float)kv[cc][j];
     acc *= scale;
     p[key] = acc;
     m = fmaxf(m, acc);
@@ -50,17 +68,15 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16* __restrict_
   __syncthreads();
   // O = P V: lane (kg, c) owns keys kg, kg + 8, ... and the 8 output dimensions 8c..8c+7; four 16-byte V loads are in
   // flight per trip (a one-key-per-iteration loop is S serial memory round trips), then the 8 key groups are summed
-  const int c = lane & 7, kg = lane >> 3;
   float o[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = 0.f;
   for (int k0 = 0; k0 < S; k0 += 32) {
-    bf16x8 vv[4];
     float w[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int key = k0 + 8 * u + kg;
-      vv[u] = *(const bf16x8*)(vb + (long)(key < S ? key : S - 1) * ld_pos + 8 * c);
+      if (k0 != 0) vv[u] = *(const bf16x8*)(vb + (long)(key < S ? key : S - 1) * ld_pos + 8 * c);
       w[u] = key < S ? p[key] : 0.f;
     }
 #pragma unroll
