@@ -78,7 +78,8 @@ def test_gemm_plain(M, N, K, akc, bkc, cfg):
 
 @pytest.mark.parametrize("act,akc,bkc", [(1, True, True), (2, True, True), (4, True, True), (18, True, True),
                                          (3, True, False), (16, True, False), (17, True, False), (19, True, False)])
-def test_gemm_epilogues(act, akc, bkc):
+@pytest.mark.parametrize("cfg", [0, 2, 3])
+def test_gemm_epilogues(act, akc, bkc, cfg):
     ops = _ops()
     M, N, K = 300, 264, 256
     g = torch.Generator(device="cuda").manual_seed(act)
@@ -96,7 +97,7 @@ def test_gemm_epilogues(act, akc, bkc):
     outb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     outp = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     ops.gemm_bf16(A, B, a_kcontig=akc, b_kcontig=bkc, alpha=0.5, bias=bias, act=act, aux=aux if act >= 16 else None,
-                  residual=res, out_f32=out, out_bf16=outb, out_pre=outp)
+                  residual=res, out_f32=out, out_bf16=outb, out_pre=outp, tile_config=cfg)
     torch.cuda.synchronize()
     _report(f"act{act} f32", out, ref, 2e-3)
     _report(f"act{act} bf16", outb, ref, 1e-2)
