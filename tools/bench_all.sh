@@ -1,3 +1,4 @@
+# every bench.py mode quoted in DESIGN.md section 6, one after the other (run on the GPU box via gpurun)
 set -e
 o=gpurun_out/final
 mkdir -p $o

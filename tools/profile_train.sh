@@ -1,3 +1,4 @@
+# rocprofv3 kernel-trace summaries of the default and the single-stream train step (run on the GPU box via gpurun; copies go to profiles/)
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
