@@ -46,6 +46,13 @@ __device__ __forceinline__ bf16x8 frag5(const char* tile, int row0, int lane) {
   return *(const bf16x8*)(tile + line * 128 + ((slot ^ (line & 7)) << 4));
 }
 
+// timing-only ablation build (tools/micro/cfg5_ablate.py; results are wrong by construction): -DCCLIP_CFG5_ABLATE=mask with
+// 1 = no in-loop DMA, 2 = no fragment refresh, 4 = no per-step wait + barrier, 8 = no epilogue
+#ifdef CCLIP_CFG5_ABLATE
+#define ABL5 CCLIP_CFG5_ABLATE
+#else
+#define ABL5 0
+#endif
 #define W5_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
 
 template <int ACT>
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void gemm_deep_kernel(const GemmArgs p) {
     constexpr bool RD = decltype(rd_tag)::value, DMA = decltype(dma_tag)::value;
     const char* At = smem + ((kt + 1) & (STAGES - 1)) * STAGE5 + a_off;
     const char* Bt = smem + ((kt + 1) & (STAGES - 1)) * STAGE5 + b_off;
-    if (RD) {
+    if (RD && !(ABL5 & 4)) {
       // stage kt+1 has landed for this wave once only the younger stages' DMAs are outstanding; the barrier publishes every
       // wave's part of it and proves every wave is done reading stage kt (whose buffer the DMA below overwrites)
       int last = kt + PD; last = last < nkt - 1 ? last : nkt - 1;          // youngest stage issued so far
@@ -128,7 +135,12 @@ __global__ __launch_bounds__(512, 2) void gemm_deep_kernel(const GemmArgs p) {
     // xf[4..7]: read early, moved over at the end) - no LDS read is issued in the last 8 MFMAs of a step, so the wait at the
     // top of the next one finds them all complete.
     bf16x8 wn[2], xn[4];
-    if (RD) {
+    if (RD && (ABL5 & 2)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xn[i] = xf[4 + i];
+      wn[0] = wf[2]; wn[1] = wf[3];
+    }
+    if (RD && !(ABL5 & 2)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) xn[i] = frag5(At, 16 * (4 + i), lane);
       wn[0] = frag5(Bt, b_row + 32, lane); wn[1] = frag5(Bt, b_row + 48, lane);
@@ -140,8 +152,8 @@ __global__ __launch_bounds__(512, 2) void gemm_deep_kernel(const GemmArgs p) {
     for (int mt = 0; mt < MT; ++mt) {
       acc[mt][2] = CCLIP_MFMA_16x16x32(wf[2], xf[mt], acc[mt][2]);
       acc[mt][3] = CCLIP_MFMA_16x16x32(wf[3], xf[mt], acc[mt][3]);
-      if (RD && mt < 4) xf[mt] = frag5(At, 16 * mt, lane);
-      if (DMA && mt >= 4) dma(kt + 1 + PD, mt - 4);
+      if (RD && mt < 4 && !(ABL5 & 2)) xf[mt] = frag5(At, 16 * mt, lane);
+      if (DMA && mt >= 4 && !(ABL5 & 1)) dma(kt + 1 + PD, mt - 4);
     }
     if (RD) {
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm_deep_kernel(const GemmArgs p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int n0 = bn0 + wn0 + 32 * h + 8 * g;
-        if (m >= p.M || n0 >= p.N) continue;
+        if (m >= p.M || n0 >= p.N || ((ABL5 & 8) && p.alpha != 123.f)) continue;
         float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
