@@ -95,11 +95,11 @@ def _launch_gemm(d) -> None:
 
 
 def _time_desc(d, reps: int = 3) -> float:
-    """best of two timed groups after two warm-up launches: one noisy sample must not pin a slow configuration for the run"""
+    """best of three timed groups after two warm-up launches: one noisy sample must not pin a slow configuration for the run"""
     _launch_gemm(d)
     _launch_gemm(d)
     best = float("inf")
-    for _ in range(2):
+    for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -115,6 +115,10 @@ def _autotune(d, key, outs, candidates):
     GEMMs (x += ...) are not applied more than once."""
     saved = (d.out_f32, d.out_bf16, d.out_pre_bf16, d.tile_config, d.split_k, d.split_ws)
     saved_cs = (d.colsum_out, d.colsum_accumulate)
+    # the trials must have the GPU to themselves: with two tower streams the other tower's kernels are still running when
+    # this one meets a new shape, and a candidate timed next to them can lose to a slower one timed alone
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
     cs_tmp = None
     if d.colsum_out:                        # trial launches must not touch (or accumulate into) the real bias gradient
         cs_tmp = torch.empty(max(d.M, d.N), device="cuda", dtype=torch.float32)
