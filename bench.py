@@ -144,8 +144,8 @@ def caption_main(args, rank, world, dev, B, cdt):
         opt.zero_grad()
         loss = model.caption_loss(tokens, prefix, attribute, mask)
         loss.backward()
-        parallel.allreduce_gradients(model, None)
-        opt.step(grad_scale=1.0 / world)        # every rank's loss is its local mean: average the summed gradients
+        # every rank's loss is its local mean: average the summed gradients; AdamW runs bucket by bucket under the all-reduce
+        opt.step(grad_scale=1.0 / world, pending=parallel.allreduce_gradients_async(model, None))
         sched.step()
         return loss
 
@@ -294,8 +294,7 @@ def main():
         fi, ft = encode_both()
         loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale, group)
         loss.backward()
-        parallel.allreduce_gradients(model, group)
-        opt.step()
+        opt.step(pending=parallel.allreduce_gradients_async(model, group))   # AdamW bucket i under the all-reduce of bucket i+1
         sched.step()
         return stats
 

@@ -32,17 +32,29 @@ class AdamW:
             self._v = torch.zeros_like(arena.flat)
         return arena
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def step(self, grad_scale: float = 1.0, pending=None) -> None:
+        """pending: [(start, end, work)] from parallel.allreduce_gradients_async - the arena is then updated range by range,
+        each as soon as its all-reduce has finished (the ranges must cover the arena; same result as one pass)."""
         arena = self._state()
         g = self.param_groups[0]
         self.step_count += 1
-        # parameters that never received a gradient keep a zero slot -> no update beyond decay (as HF skips them)
-        for n, p in arena.params.items():
-            if p.grad is None:
-                arena.g[n].zero_()
-        ops.adamw_step(arena.flat, arena.gflat, self._m, self._v, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1],
-                       eps=g["eps"], weight_decay=g["weight_decay"], step=self.step_count,
-                       correct_bias=g["correct_bias"], grad_scale=grad_scale, mode=self.mode, bf16_shadow=arena.bflat)
+        # parameters that never received a gradient keep a zero slot -> no update beyond decay (as HF skips them).
+        # (With pending reductions every rank takes the same branch: p.grad is None depends on the model, not on the data.)
+        none = [n for n, p in arena.params.items() if p.grad is None]
+        if none and pending:
+            for _, _, w in pending:
+                w.wait()
+        for n in none:
+            arena.g[n].zero_()
+        kw = dict(lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                  step=self.step_count, correct_bias=g["correct_bias"], grad_scale=grad_scale, mode=self.mode)
+        if pending:
+            assert pending[0][0] == 0 and pending[-1][1] == arena.total and all(a[1] == b[0] for a, b in zip(pending, pending[1:]))
+            for s, e, w in pending:
+                w.wait()
+                ops.adamw_step(arena.flat[s:e], arena.gflat[s:e], self._m[s:e], self._v[s:e], bf16_shadow=arena.bflat[s:e], **kw)
+        else:
+            ops.adamw_step(arena.flat, arena.gflat, self._m, self._v, bf16_shadow=arena.bflat, **kw)
         arena.mark_shadows_fresh()            # the kernel rewrote masters and shadows together
 
     def zero_grad(self, set_to_none: bool = True) -> None:

@@ -57,6 +57,17 @@ def allreduce_gradients(model, group=None, max_bucket_elems: int = 64 << 20, asy
     return works if async_op else []
 
 
+def allreduce_gradients_async(model, group=None, max_bucket_elems: int = 32 << 20):
+    """The same bucketed SUM all-reduce, issued asynchronously: returns [(start, end, work)] in bucket order for
+    `optim.AdamW.step(pending=...)`, which waits for bucket i, updates its range and lets RCCL reduce bucket i+1 meanwhile
+    (the fused optimiser is one ~1 ms pass over the arena: most of it then runs under the collective).  World size 1: []."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return []
+    arena = model.arena if hasattr(model, "arena") else model
+    return [(s, e, dist.all_reduce(arena.gflat[s:e], group=group, async_op=True))
+            for s, e in grad_buckets(arena, max_bucket_elems)]
+
+
 def broadcast_parameters(model, src: int = 0, group=None) -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         arena = model.arena if hasattr(model, "arena") else model

@@ -48,3 +48,20 @@ def reduce_dot(a, b, out, *, alpha=1.0, mul_dev=None, accumulate=False):
     v = (a * b).sum() if b is not None else a.sum()
     v = v * alpha * (1.0 if mul_dev is None else mul_dev.item())
     out.copy_((out + v) if accumulate else v.reshape(out.shape))
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.0, step=1,
+               correct_bias=True, grad_scale=1.0, mode=0, bf16_shadow=None):
+    """transformers.AdamW (mode 0) on flat views, in place - the contract of cclip_adamw_step (include/cclip_hip.h)."""
+    assert mode == 0
+    g = grad * grad_scale
+    exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
+    exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    step_size = lr
+    if correct_bias:
+        step_size = lr * (1 - beta2 ** step) ** 0.5 / (1 - beta1 ** step)
+    param.addcdiv_(exp_avg, exp_avg_sq.sqrt().add_(eps), value=-step_size)
+    if weight_decay > 0:
+        param.add_(param, alpha=-lr * weight_decay)
+    if bf16_shadow is not None:
+        bf16_shadow.copy_(param)

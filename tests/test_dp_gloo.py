@@ -44,8 +44,34 @@ def _worker(rank, world, port, out_dir):
     ar = ParamArena(m, torch.device("cpu"))
     ar.gflat.copy_(torch.arange(ar.total, dtype=torch.float32) * (rank + 1))
     par.allreduce_gradients(ar, max_bucket_elems=300_000)
-    torch.save(dict(loss=loss.detach(), stats=stats, dfi=fi.grad, dft=ft.grad, dls=lsp.grad,
-                    gsum_ok=torch.equal(ar.gflat, torch.arange(ar.total, dtype=torch.float32) * 3)),
+    gsum_ok = torch.equal(ar.gflat, torch.arange(ar.total, dtype=torch.float32) * 3)
+    # asynchronous buckets + range-by-range AdamW == synchronous all-reduce + one AdamW pass
+    import clip.optim as coptim
+    coptim.ops = cpu_ops_shim
+
+    class _M:                                      # the two attributes AdamW uses
+        def __init__(self, arena): self.arena = arena
+        def parameters(self): return list(self.arena.params.values())
+    res = []
+    for use_async in (False, True):
+        torch.manual_seed(5)
+        mm = clip.CLIP(MODELS["test-tiny"]).initialize_parameters(1)
+        a2 = ParamArena(mm, torch.device("cpu"))
+        for n_, p_ in a2.params.items():
+            p_.grad = a2.g[n_]                     # every parameter "has a gradient": its arena slot
+        a2.gflat.copy_(torch.sin(torch.arange(a2.total, dtype=torch.float32) * 0.37 + rank))
+        opt = coptim.AdamW(_M(a2), lr=1e-3)
+        for _ in range(2):
+            if use_async:
+                pend = par.allreduce_gradients_async(a2, max_bucket_elems=300_000)
+                assert len(pend) > 1
+                opt.step(grad_scale=0.5, pending=pend)
+            else:
+                par.allreduce_gradients(a2, max_bucket_elems=300_000)
+                opt.step(grad_scale=0.5)
+        res.append(a2.flat.clone())
+    async_ok = torch.equal(res[0], res[1]) and not torch.equal(res[0], ParamArena(clip.CLIP(MODELS["test-tiny"]).initialize_parameters(1), torch.device("cpu")).flat)
+    torch.save(dict(loss=loss.detach(), stats=stats, dfi=fi.grad, dft=ft.grad, dls=lsp.grad, gsum_ok=gsum_ok, async_ok=async_ok),
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -73,6 +99,7 @@ def test_dp_contrastive_matches_single_process(tmp_path):
         assert torch.allclose(o["dfi"], fi.grad[r * nloc:(r + 1) * nloc], atol=1e-6)
         assert torch.allclose(o["dft"], ft.grad[r * nloc:(r + 1) * nloc], atol=1e-6)
         assert o["gsum_ok"]
+        assert o["async_ok"]                                         # bucket-wise AdamW under async all-reduce == one pass
     assert abs(dls.item() - ls.grad.item()) < 1e-6
 
 
