@@ -7,15 +7,16 @@
 //
 //   C[m*ldc + n] = alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + beta * C[m*ldc + n]
 //
-// 64x64x16 tile, 4 waves (2x2), each wave 32x32 as 2x2 MFMA tiles; operands staged through LDS
+// 32x32x32 tile, 4 waves (2x2), each wave one 16x16 MFMA tile; operands staged through LDS
 // (+1-padded rows).  The MFMA is issued swapped (B as the A operand) so each lane ends up with
 // 4 consecutive n of one m -> 16-byte stores.
 #include "cclip_common.h"
 #include "../../include/cclip_hip.h"
 
-#define FBM 64
-#define FBN 64
-#define FBK 16
+#define FWT 1                 // MFMA tiles per wave and dimension: a 32x32 block tile -> 4x the workgroups of a 64x64 one
+#define FBM (32 * FWT)        // (these GEMMs are 1 GFLOP on a 256-CU chip: latency-bound, so occupancy beats operand reuse)
+#define FBN (32 * FWT)
+#define FBK 32
 #define FLD (FBK + 1)
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak,
@@ -26,53 +27,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int bm0 = blockIdx.y * FBM, bn0 = blockIdx.x * FBN;
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-  f32x4 acc[2][2];
+  const int wm0 = (wave >> 1) * 16 * FWT, wn0 = (wave & 1) * 16 * FWT;
+  f32x4 acc[FWT][FWT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FWT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FWT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool a_kfast = sak == 1, b_kfast = sbk == 1;
-  // register-staged prefetch: the global loads of K-tile k0+16 are in flight while tile k0 is multiplied
-  float ra[4], rb[4];
+  // register-staged prefetch: the global loads of K-tile k0+FBK are in flight while tile k0 is multiplied
+  constexpr int NL = FBM * FBK / 256;                        // elements per thread per operand tile
+  float ra[NL], rb[NL];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int idx = tid + 256 * i;
       int m, k;
-      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
+      if (a_kfast) { m = idx / FBK; k = idx % FBK; } else { k = idx / FBM; m = idx % FBM; }
       ra[i] = (bm0 + m < M && k0 + k < K) ? A[(long)(bm0 + m) * sam + (long)(k0 + k) * sak] : 0.f;
       int n, kb;
-      if (b_kfast) { n = idx >> 4; kb = idx & 15; } else { kb = idx >> 6; n = idx & 63; }
+      if (b_kfast) { n = idx / FBK; kb = idx % FBK; } else { kb = idx / FBN; n = idx % FBN; }
       rb[i] = (bn0 + n < N && k0 + kb < K) ? B[(long)(bn0 + n) * sbn + (long)(k0 + kb) * sbk] : 0.f;
     }
   };
   gload(0);
   for (int k0 = 0; k0 < K; k0 += FBK) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int idx = tid + 256 * i;
       int m, k;
-      if (a_kfast) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
+      if (a_kfast) { m = idx / FBK; k = idx % FBK; } else { k = idx / FBM; m = idx % FBM; }
       As[m * FLD + k] = ra[i];
       int n, kb;
-      if (b_kfast) { n = idx >> 4; kb = idx & 15; } else { kb = idx >> 6; n = idx & 63; }
+      if (b_kfast) { n = idx / FBK; kb = idx % FBK; } else { kb = idx / FBN; n = idx % FBN; }
       Bs[n * FLD + kb] = rb[i];
     }
     __syncthreads();
     if (k0 + FBK < K) gload(k0 + FBK);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float af[2], bf[2];
+    for (int kk = 0; kk < FBK / 4; ++kk) {
+      float af[FWT], bf[FWT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < FWT; ++t) {
         af[t] = As[(wm0 + 16 * t + li) * FLD + 4 * kk + g];
         bf[t] = Bs[(wn0 + 16 * t + li) * FLD + 4 * kk + g];
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < FWT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < FWT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);
     }
     __syncthreads();
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   // D[i = 4g + r][j = li]: i <-> n (from the B-side operand), j <-> m
   // beta != 0 (gradient accumulation): all 16 previous values are requested first, clamped in-bounds so that no load is
   // predicated - a per-element load -> fma -> store chain is 16 serial memory round trips
-  float prev[2][2][4];
+  float prev[FWT][FWT][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < FWT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < FWT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         prev[mt][nt][r] = 0.f;
@@ -95,11 +97,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
       }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < FWT; ++mt) {
     const int m = bm0 + wm0 + 16 * mt + li;
     if (m >= M) continue;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < FWT; ++nt) {
       const int n0 = bn0 + wn0 + 16 * nt + 4 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
