@@ -4,5 +4,4 @@ from .clip import available_models, load, tokenize, _transform  # noqa: F401
 from . import simple_tokenizer  # noqa: F401  (attention.py:114 uses clip.simple_tokenizer.SimpleTokenizer)
 from .model import CLIP, build_model  # noqa: F401
 from .loss import contrastive_loss, ContrastiveLoss  # noqa: F401
-from .graphs import GraphedCallable, graphed_encoders  # noqa: F401
 from .preprocess_device import DevicePreprocess  # noqa: F401

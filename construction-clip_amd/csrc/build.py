@@ -17,10 +17,6 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libcclip_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
-if os.environ.get("CCLIP_BUILD_VARIANT") == "stamps":      # diagnostics-only library for tools/gemm_stamps.py (per-tile phase timestamps)
-    FLAGS.append("-DCCLIP_GEMM_STAMPS")
-    OBJ_DIR = os.path.join(HERE, "build_stamps")
-    LIB = os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools", "micro", "_bin", "libcclip_hip_stamps.so")
 
 
 def _sources():

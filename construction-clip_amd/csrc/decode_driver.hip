@@ -28,9 +28,6 @@ bool ln_gemv(const float* x, int64_t ldx, const float* gamma, const float* beta,
   a.A = nullptr; a.B = (const bf16*)W; a.lda = 0; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.ktiles_per_split = 0;
   a.alpha = 1.0f; a.bias = bias; a.residual = nullptr; a.ldr = 0; a.aux = nullptr; a.ldaux = 0;
   a.out_f32 = nullptr; a.out_bf16 = (bf16*)out16; a.out_pre = nullptr; a.ldc = ldc; a.act = act; a.split_ws = nullptr;
-#ifdef CCLIP_GEMM_STAMPS
-  a.stamps = nullptr;
-#endif
   a.ln_x = x; a.ln_ldx = ldx; a.ln_gamma = gamma; a.ln_beta = beta;
   a.kv_k = (bf16*)kv_k; a.kv_v = (bf16*)kv_v; a.kv_ld_seq = kv_ld_seq; a.kv_width = kv_width;
   return cclip_gemm_launch_skinny(2, act, stream, a);

@@ -35,7 +35,6 @@ bool cclip_gemm_launch_cfg1(int lay, int act, dim3 grid, hipStream_t stream, con
 bool cclip_gemm_launch_cfg2(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg3(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg4(int lay, int act, hipStream_t stream, const GemmArgs& a);
-bool cclip_gemm_launch_cfg5(int lay, int act, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmArgs& a);
 
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
@@ -99,10 +98,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }  // namespace CCLIP_NS
 using namespace CCLIP_NS;
 
-#ifdef CCLIP_GEMM_STAMPS
-static unsigned long long* g_stamps = nullptr;
-extern "C" void CCLIP_FN(cclip_gemm_debug_set_stamps)(void* buf) { g_stamps = (unsigned long long*)buf; }
-#endif
 
 extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return CCLIP_ERR_ARG;
@@ -133,9 +128,6 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     a.colsum_dst = d->colsum_out; a.colsum_acc = d->colsum_accumulate; a.colsum_b = d->colsum_of_b ? 1 : 0;
     a.colsum_ws = splits > 1 ? d->split_ws + (size_t)splits * d->M * d->N : nullptr;
   }
-#ifdef CCLIP_GEMM_STAMPS
-  a.stamps = g_stamps;
-#endif
 
   int cfg = d->tile_config;
   // M <= 8 against K-strided weights (the projections of a KV-cached decode step): weight-read-bound GEMV path
@@ -143,10 +135,6 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     return cclip_launch_status();
   if (cfg == 4) {     // persistent streaming-epilogue kernel: forward layout, full tiles only - refused (not silently replaced) otherwise
     if (splits > 1 || !cclip_gemm_launch_cfg4(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
-    return cclip_launch_status();
-  }
-  if (cfg == 5) {     // 256x256, BK = 32, four LDS stages: forward layout, unsplit - refused otherwise
-    if (splits > 1 || !cclip_gemm_launch_cfg5(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
     return cclip_launch_status();
   }
   if (cfg <= 0 || cfg > 3) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);

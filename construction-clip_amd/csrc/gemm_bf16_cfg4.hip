@@ -1,7 +1,7 @@
 // tile configuration 4 ("streaming"): PERSISTENT 256x128 workgroups (8 waves of 64x64, 3 LDS stages) for the forward
 // layout, whose epilogue is streamed out under the NEXT tile's K loop.
 //
-// Why (tools/gemm_stamps.py timelines): with one tile per workgroup a tile lives 17-23 us of which
+// Why (round-1 in-kernel timelines): with one tile per workgroup a tile lives 17-23 us of which
 // only 10-12 us are K loop - the fill (first operand tiles, residual rows) and the epilogue stores are HBM time during
 // which the matrix pipe idles, and they do not overlap across workgroups either.  Here a workgroup walks a static list
 // of tiles: the operand DMA runs PD = 2 K-tiles ahead ACROSS tile boundaries (no fill bubble after the first tile), and

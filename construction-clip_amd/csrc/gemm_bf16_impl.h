@@ -32,19 +32,8 @@ struct GemmArgs {
   // with split-K the raw partials go to colsum_ws[z][M] and the combine kernel finishes them
   float* colsum_dst = nullptr; float* colsum_ws = nullptr; int colsum_acc = 0;
   int colsum_b = 0;   // 1: row sums of B (size N) instead - the Conv1D weight layout, where dY is the B operand
-#ifdef CCLIP_GEMM_STAMPS
-  unsigned long long* stamps;   // diagnostics build only: [tile][8] = hw id, t_start, t_issued, t_first, t_kdone, t_end (100 MHz)
-#endif
 };
 
-#ifdef CCLIP_GEMM_STAMPS
-#define STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (i)] = wall_clock64(); } while (0)
-// fine stamps (core clock) of K iteration kt0+5, lane 0 of every wave: region after the per-tile records, [tile][wave 0..7][8]
-#define ISTAMP(i) do { if (p.stamps && kt == kt0 + 5 && lane == 0) p.stamps[(size_t)gridDim.x * gridDim.y * 8 + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#define ISTAMP(i) do {} while (0)
-#endif
 
 // n-permutation: position i (0..15) of MFMA n-tile nt (0..3) of a wave's 64-column block maps to
 // local column P = 8*(i>>2) + 32*(nt>>1) + 4*(nt&1) + (i&3).  With the accumulator map
@@ -223,15 +212,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   const int wm0 = wm * 16 * MT, wn0 = wn * 64;                    // offsets inside the block tile
   const int a_off = (wm0 >> 7) * TILE_BYTES, a_row = wm0 & 127;   // sub-tile + row/col offset inside it
   const int b_off = (wn >> 1) * TILE_BYTES, b_row = (wn & 1) * 64;
-
-#ifdef CCLIP_GEMM_STAMPS
-  if (p.stamps && threadIdx.x == 0) {
-    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    p.stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8] = ((unsigned long long)xcc << 32) | hw;
-  }
-#endif
-  STAMP(1);
   f32x4 acc[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -263,7 +243,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt0 + s) * BK, sb + NSA * TILE_BYTES, wave, lane);
     }
   }
-  STAMP(2);
   int cur = 0;                                                   // stage holding tile kt
   constexpr bool WG_LAYOUT = !A_KC && !B_KC && MT <= 4;     // (the 128x64-per-wave kernels have no registers left for it)
   f32x4 accb[WG_LAYOUT ? MT : 1];
@@ -274,8 +253,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   for (int i = 0; i < (WG_LAYOUT ? MT : 1); ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // One K-tile iteration.  DMA = true (steady state, kt + PD < kt1): the operand DMA of tile kt+PD is part of the same
   // basic block as the MFMAs and is dealt out BETWEEN them (one global_load_lds per few MFMAs): issuing the 6-8 DMA
-  // instructions back to back cost ~500 clocks per wave per iteration with the matrix pipe idle (in-kernel stamps,
-  // tools/gemm_stamps.py), almost as much as the iteration's MFMAs themselves.  DMA = false: the last PD iterations.
+  // instructions back to back cost ~500 clocks per wave per iteration with the matrix pipe idle (round-1 in-kernel
+  // timestamps), almost as much as the iteration's MFMAs themselves.  DMA = false: the last PD iterations.
   auto k_iter = [&](int kt, auto dma_tag, auto cs_tag, int wait_tiles) {
     constexpr bool DMA = decltype(dma_tag)::value;
     constexpr int CS = decltype(cs_tag)::value;            // 0: none; 1: row sums of A; 2: row sums of B
@@ -288,22 +267,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     constexpr bool ILV_EARLY = !ILV && MT >= 8;
     // tile kt has landed for this wave once at most the younger stages' DMAs are outstanding; the barrier then
     // (a) publishes every wave's part of tile kt and (b) proves every wave is done reading stage cur-1
-    ISTAMP(0);
-#ifdef CCLIP_GEMM_STAMPS
-    if (kt == kt0 + 5) {      // split the wait from the barrier for the instrumented iteration
-      if (PD >= 3 && wait_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-      else if (PD >= 2 && wait_tiles >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ISTAMP(1);
-    }
-#endif
     if (PD >= 3 && wait_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
     else if (PD >= 2 && wait_tiles >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef CCLIP_GEMM_STAMPS
-    if (kt == kt0) STAMP(3);
-#endif
-    ISTAMP(2);
     if (DMA && !ILV && !ILV_EARLY) {
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
@@ -340,7 +306,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
     }
-    ISTAMP(3);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -388,10 +353,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       }
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
-#ifdef CCLIP_GEMM_STAMPS
-    __builtin_amdgcn_sched_barrier(0);
-    ISTAMP(4);
-#endif
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   };
   int kt = kt0;
@@ -435,8 +396,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
         }
     }
   }
-
-  STAMP(4);
   // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
   // Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then the
   // math and the stores - one memory round trip per batch instead of one per 8-column run.
@@ -510,11 +469,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       }
     }
   }
-  STAMP(5);
-#ifdef CCLIP_GEMM_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  STAMP(6);
-#endif
 }
 
 // launcher for one tile configuration; instantiates exactly the (layout, activation) pairs the hot path issues

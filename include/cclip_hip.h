@@ -81,9 +81,6 @@ typedef struct cclip_gemm_desc {
                         * 4 = persistent 256x128 with the epilogue streamed under the next tile's K loop - forward layout,
                         *     M % 256 == 0, N % 128 == 0, N <= 4096, K >= 512 (640 with a residual), one of the three
                         *     epilogue forms {16-bit out | pre-activation + activation | fp32 out + residual}; status 1 otherwise.
-                        * 5 = 256x256 with 32-deep LDS stages (four of them; operand DMA four k-steps ahead of its MFMAs) - forward
-                        *     layout, K % 32 == 0, operands < 2 GiB, split_k <= 1, no aux operand, activation none / QuickGELU;
-                        *     status 1 otherwise.  Measured equal to 3; not an autotuner candidate.
                         * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
   /* wgrad layout (0,0) only: colsum_out[m] (+)= sum_k A(m,k) - the BIAS gradient of the layer whose weight gradient this
    * call computes (A = dY^T), taken off the operand tiles already in LDS by one extra MFMA per m-tile against an all-ones

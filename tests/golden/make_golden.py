@@ -119,15 +119,27 @@ def caption_tmapper_case(name: str, b: int, lc: int, seed: int, clip_length: int
                 grad_norms={k: v.grad.norm() for k, v in sdg.items() if v.grad is not None and k.startswith("clip_project.")})
 
 
+CASES = {
+    "clip_test_tiny.pt": lambda: clip_case("test-tiny", 9, 11, True),
+    "clip_test_small.pt": lambda: clip_case("test-small", 9, 12, True),
+    # BASELINE configs[1] geometry WITH gradients (round 2: the benched workload's backward against the oracle)
+    "clip_vit_b32.pt": lambda: clip_case("ViT-B/32", 9, 567, True),
+    "clip_test_long.pt": lambda: clip_case("test-long", 9, 13, True),
+    "clip_vit_l14_336.pt": lambda: image_only_case("ViT-L/14@336px", 2, 567),
+    "caption_test_tiny.pt": lambda: caption_case("test-tiny", 3, 12, 21),
+    "caption_tmapper_tiny.pt": lambda: caption_tmapper_case("test-tiny", 3, 12, 23, clip_length=6, num_layers=2),
+    # BASELINE configs[3] at its real geometry: GPT-2-small (V = 21128, 12 layers), mapper 512 -> 7680 -> 15360, P = A = 20,
+    # Lc = 40 -> S = 80 (/root/reference/CLIP_prefix_caption/train.py:277-279, 354-357)
+    "caption_gpt2_base_chinese.pt": lambda: caption_case("ckiplab/gpt2-base-chinese", 2, 40, 31),
+}
+
+
 def main():
+    """python tests/golden/make_golden.py [file.pt ...]   (no arguments: every case)"""
     torch.manual_seed(0)
-    torch.save(clip_case("test-tiny", 9, 11, True), os.path.join(OUT, "clip_test_tiny.pt"))
-    torch.save(clip_case("test-small", 9, 12, True), os.path.join(OUT, "clip_test_small.pt"))
-    torch.save(clip_case("ViT-B/32", 9, 567, False), os.path.join(OUT, "clip_vit_b32.pt"))
-    torch.save(clip_case("test-long", 9, 13, True), os.path.join(OUT, "clip_test_long.pt"))
-    torch.save(image_only_case("ViT-L/14@336px", 2, 567), os.path.join(OUT, "clip_vit_l14_336.pt"))
-    torch.save(caption_case("test-tiny", 3, 12, 21), os.path.join(OUT, "caption_test_tiny.pt"))
-    torch.save(caption_tmapper_case("test-tiny", 3, 12, 23, clip_length=6, num_layers=2), os.path.join(OUT, "caption_tmapper_tiny.pt"))
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        torch.save(CASES[n](), os.path.join(OUT, n))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -20,7 +20,7 @@ def _model(name="test-small"):
 
 def test_graphed_encoders_match_eager_and_handle_new_shapes():
     clip, geo, model, synthetic_images, synthetic_text = _model()
-    enc_i, enc_t = clip.graphed_encoders(model)
+    enc_i, enc_t = graphed_encoders(model)
     for n, seed in ((1, 1), (4, 2), (1, 3), (4, 4)):                 # shapes repeat: the second visit replays the first's graph
         img = synthetic_images(n, geo, seed).cuda()
         txt = synthetic_text(n, geo, seed).cuda()
@@ -34,7 +34,7 @@ def test_graphed_encoders_match_eager_and_handle_new_shapes():
 def test_graph_replay_latency_for_one_image():
     """application.py:97 / parse_coco.py:43 encode one image per call: ~150 launches of microsecond kernels."""
     clip, geo, model, synthetic_images, _ = _model("ViT-B/32")
-    enc_i, _ = clip.graphed_encoders(model)
+    enc_i, _ = graphed_encoders(model)
     img = synthetic_images(1, geo, 5).cuda()
     with torch.no_grad():
         for _ in range(3):
