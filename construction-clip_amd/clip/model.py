@@ -398,25 +398,36 @@ class CLIP(nn.Module):
             return _TextTower.apply(self, text, *[self._arena.params[n] for n in names])
         return self._text_forward(text, train=False)[0]
 
+    def _tower_streams(self, device):
+        if self._rt.get("streams") is None:
+            self._rt["streams"] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return self._rt["streams"]
+
     def encode_image_text(self, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Both towers, on two HIP streams (CCLIP_TOWER_STREAMS=1 disables): they are independent until the logits,
-        and their kernels' store phases and MFMA phases interleave on the CUs (~5 % on the bs=1024 step).  autograd
-        replays each tower's backward on the stream its forward ran on."""
+        and their kernels' store phases and MFMA phases interleave on the CUs (~5 % on the bs=1024 step).  In a
+        training step the pair is ONE autograd node (_BothTowers) that forks to the two streams and joins back onto the
+        caller's stream in forward and in backward, so every gradient slot of the arena is complete, in stream order,
+        before anything the caller enqueues after `backward()` (optimizer, gradient all-reduce, a .grad reader)."""
         import os
         _require_cuda(image, "encode_image_text")
         if os.environ.get("CCLIP_TOWER_STREAMS", "2") != "2":
             return self.encode_image(image), self.encode_text(text)
         self._ensure_runtime()
         self._arena.refresh_shadows()                # on the current stream, before the fork
-        if self._rt.get("streams") is None:
-            self._rt["streams"] = (torch.cuda.Stream(device=image.device), torch.cuda.Stream(device=image.device))
-        s0, s1 = self._rt["streams"]
+        names = self._rt["vis_names"] + self._rt["txt_names"]
+        train = torch.is_grad_enabled()
+        if train and all(self._arena.params[n].requires_grad for n in names):
+            return _BothTowers.apply(self, image, text, *[self._arena.params[n] for n in names])
+        if train and any(self._arena.params[n].requires_grad for n in names):
+            return self.encode_image(image), self.encode_text(text)      # partly frozen model: one stream, plain nodes
+        s0, s1 = self._tower_streams(image.device)
         cur = torch.cuda.current_stream()
         s0.wait_stream(cur); s1.wait_stream(cur)
         with torch.cuda.stream(s0):
-            fi = self.encode_image(image)
+            fi = self._image_forward(image, train=False)[0]
         with torch.cuda.stream(s1):
-            ft = self.encode_text(text)
+            ft = self._text_forward(text, train=False)[0]
         cur.wait_stream(s0); cur.wait_stream(s1)
         fi.record_stream(cur); ft.record_stream(cur)
         return fi, ft
@@ -461,6 +472,47 @@ class _TextTower(torch.autograd.Function):
         ctx.model._text_backward(ctx.c, dfeat)
         ctx.c = None
         return (None, None) + (None,) * ctx.n
+
+
+class _BothTowers(torch.autograd.Function):
+    """encode_image + encode_text of one training step on the two tower streams, with an EXPLICIT fork / join around both
+    the forward and the backward kernel sequences.  The backward writes parameter gradients into the arena as a side effect
+    (parameter inputs get None back), so nothing in autograd would order a consumer of those slots behind the tower
+    streams; the join at the end of backward() does, on the stream autograd runs this node on (= the stream of forward)."""
+
+    @staticmethod
+    def forward(ctx, model: CLIP, image, text, *params):
+        s0, s1 = model._tower_streams(image.device)
+        cur = torch.cuda.current_stream()
+        s0.wait_stream(cur); s1.wait_stream(cur)
+        with torch.cuda.stream(s0):
+            fi, ci = model._image_forward(image, train=True)
+        with torch.cuda.stream(s1):
+            ft, ct = model._text_forward(text, train=True)
+        cur.wait_stream(s0); cur.wait_stream(s1)
+        fi.record_stream(cur); ft.record_stream(cur)
+        ctx.model, ctx.ci, ctx.ct, ctx.n = model, ci, ct, len(params)
+        ctx.set_materialize_grads(False)
+        return fi, ft
+
+    @staticmethod
+    def backward(ctx, dfi, dft):
+        model = ctx.model
+        dev = (dfi if dfi is not None else dft).device
+        s0, s1 = model._tower_streams(dev)
+        cur = torch.cuda.current_stream()
+        s0.wait_stream(cur); s1.wait_stream(cur)
+        if dfi is not None:
+            with torch.cuda.stream(s0):
+                dfi.record_stream(s0)
+                model._image_backward(ctx.ci, dfi)
+        if dft is not None:
+            with torch.cuda.stream(s1):
+                dft.record_stream(s1)
+                model._text_backward(ctx.ct, dft)
+        cur.wait_stream(s0); cur.wait_stream(s1)      # the join: every gradient slot is final on the caller's stream
+        ctx.ci = ctx.ct = None
+        return (None, None, None) + (None,) * ctx.n
 
 
 def normalized_logits(fi: torch.Tensor, ft: torch.Tensor, logit_scale: torch.Tensor):

@@ -57,61 +57,96 @@ def extract_embeddings(model, annotations: Sequence[dict], load_image: Callable[
     return torch.cat(feats, dim=0), out
 
 
+def _pad_rows(rows: Sequence[torch.Tensor], width: int) -> torch.Tensor:
+    """[len(rows), width] int64: every row cut to `width` and right-padded with id 0."""
+    out = torch.zeros(len(rows), width, dtype=torch.int64)
+    for i, r in enumerate(rows):
+        n = min(int(r.shape[0]), width)
+        out[i, :n] = r[:n]
+    return out
+
+
 class ClipCocoDataset(Dataset):
+    """Caption-trainer dataset with the reference's interface (train.py:27-107) and a dense layout: everything
+    `pad_tokens` decides per visit in the reference is decided ONCE here, into three tensors
+
+        tokens     [N, max_seq_len]            int64   caption ids cut / zero-padded to max_seq_len, negative ids -> 0
+        attributes [N, attribute_length]       int64   attribute ids cut / zero-padded
+        masks      [N, P + A + max_seq_len]    float   ones over prefix + attribute, then (original id >= 0)
+
+    so `__getitem__` is four row views (a DataLoader worker collates them without touching Python lists) and a whole epoch can
+    be moved to the device with `.tensors()`.  `max_seq_len = min(int(mean + 10 std), max)` over the caption lengths.
+    Pinned against the reference's own `pad_tokens` / `__getitem__` on hand-made token lists
+    (tests/golden/ref_pad_tokens.pt).  One reference behaviour is deliberately not reproduced: it zeroes negative ids inside
+    the list it caches, so from the SECOND visit of such an item on its mask is all ones; here the mask of an item is the same
+    every epoch (tokenizer ids are never negative, so the two only differ on hand-made inputs)."""
+
     def __init__(self, data_path: str, prefix_length: int, attribute_length: int, gpt2_type: str = "", normalize_prefix=False,
                  tokenizer=None, write_tokens_cache: bool = True):
         if tokenizer is None:
             from transformers import AutoTokenizer                      # train.py:67 (needs local files: no network here)
             tokenizer = AutoTokenizer.from_pretrained(gpt2_type, local_files_only=True)
         self.tokenizer = tokenizer
-        self.prefix_length, self.attribute_length, self.normalize_prefix = prefix_length, attribute_length, normalize_prefix
         all_data = load_embeddings(data_path)
         print("Data size is %0d" % len(all_data["clip_embedding"]))
         sys.stdout.flush()
-        self.prefixes = all_data["clip_embedding"]
-        self.captions, self.captions_tokens, self.attributes_tokens, self.caption2embedding = [], [], [], []
-        max_seq_len = 0
-        for caption in all_data["captions"]:
-            if caption["caption"] == "":
-                caption["caption"] = caption["violation_list"]          # train.py:85-86
-            self.captions.append(caption["caption"])
-            self.captions_tokens.append(torch.tensor(self.tokenizer.encode(caption["caption"]), dtype=torch.int64))
-            self.attributes_tokens.append(torch.tensor(self.tokenizer.encode(caption["attribute"]), dtype=torch.int64))
-            self.caption2embedding.append(caption["clip_embedding"])
-            max_seq_len = max(max_seq_len, self.captions_tokens[-1].shape[0])
-        if write_tokens_cache:
-            with open(f"{data_path[:-4]}_tokens.pkl", "wb") as f:      # train.py:103-104
-                pickle.dump([self.captions_tokens, self.caption2embedding, max_seq_len], f)
-        all_len = torch.tensor([len(t) for t in self.captions_tokens]).float()
-        self.max_seq_len = min(int(all_len.mean() + all_len.std() * 10), int(all_len.max()))
+        records = all_data["captions"]
+        for rec in records:
+            if rec["caption"] == "":
+                rec["caption"] = rec["violation_list"]                  # train.py:85-86
+        self.captions = [rec["caption"] for rec in records]
+        caps = [torch.tensor(tokenizer.encode(rec["caption"]), dtype=torch.int64) for rec in records]
+        attrs = [torch.tensor(tokenizer.encode(rec["attribute"]), dtype=torch.int64) for rec in records]
+        index = [rec["clip_embedding"] for rec in records]
+        if write_tokens_cache:                                          # train.py:103-104 side effect, same payload
+            with open(f"{data_path[:-4]}_tokens.pkl", "wb") as f:
+                pickle.dump([caps, index, max((int(c.shape[0]) for c in caps), default=0)], f)
+        self._build(caps, attrs, index, all_data["clip_embedding"], prefix_length, attribute_length, normalize_prefix, None)
+
+    @classmethod
+    def from_token_lists(cls, captions_tokens: Sequence[torch.Tensor], attributes_tokens: Sequence[torch.Tensor],
+                         caption2embedding: Sequence[int], prefixes: torch.Tensor, prefix_length: int, attribute_length: int,
+                         normalize_prefix: bool = False, max_seq_len: Optional[int] = None) -> "ClipCocoDataset":
+        """The same dataset from already tokenised captions (no tokenizer / pickle involved)."""
+        ds = cls.__new__(cls)
+        ds.tokenizer, ds.captions = None, []
+        ds._build(list(captions_tokens), list(attributes_tokens), list(caption2embedding), prefixes, prefix_length,
+                  attribute_length, normalize_prefix, max_seq_len)
+        return ds
+
+    def _build(self, caps, attrs, index, prefixes, prefix_length, attribute_length, normalize_prefix, max_seq_len):
+        self.prefix_length, self.attribute_length, self.normalize_prefix = prefix_length, attribute_length, normalize_prefix
+        self.prefixes = prefixes
+        self.caption2embedding = torch.as_tensor(index, dtype=torch.int64)
+        if max_seq_len is None:
+            lens = torch.tensor([float(c.shape[0]) for c in caps])
+            max_seq_len = min(int(lens.mean() + lens.std() * 10), int(lens.max()))      # train.py:105-106
+        self.max_seq_len = max_seq_len
+        raw = _pad_rows(caps, max_seq_len)
+        valid = raw.ge(0)                                               # "mask is zero where we out of sequence"
+        self.tokens = raw * valid
+        self.attributes = _pad_rows(attrs, attribute_length)
+        self.masks = torch.cat((torch.ones(len(caps), prefix_length + attribute_length), valid.float()), dim=1)
 
     def __len__(self) -> int:
-        return len(self.captions_tokens)
+        return self.tokens.shape[0]
 
     def pad_tokens(self, item: int):
-        tokens = self.captions_tokens[item]
-        padding = self.max_seq_len - tokens.shape[0]
-        if padding > 0:
-            tokens = torch.cat((tokens, torch.zeros(padding, dtype=torch.int64)))
-        elif padding < 0:
-            tokens = tokens[:self.max_seq_len]
-        self.captions_tokens[item] = tokens
-        attribute = self.attributes_tokens[item]
-        padding = self.attribute_length - attribute.shape[0]
-        if padding > 0:
-            attribute = torch.cat((attribute, torch.zeros(padding, dtype=torch.int64)))
-        elif padding < 0:
-            attribute = attribute[:self.attribute_length]
-        self.attributes_tokens[item] = attribute
-        mask = tokens.ge(0)
-        tokens[~mask] = 0
-        mask = torch.cat((torch.ones(self.prefix_length + self.attribute_length), mask.float()), dim=0)
-        return tokens, attribute, mask
+        return self.tokens[item], self.attributes[item], self.masks[item]
 
     def __getitem__(self, item: int):
-        tokens, attribute, mask = self.pad_tokens(item)
         prefix = self.prefixes[self.caption2embedding[item]]
         if self.normalize_prefix:
             prefix = prefix.float()
             prefix = prefix / prefix.norm(2, -1)
-        return tokens, mask, prefix, attribute
+        return self.tokens[item], self.masks[item], prefix, self.attributes[item]
+
+    def tensors(self, device=None):
+        """(tokens, masks, prefixes-per-item, attributes) of the whole set, optionally on `device`: with 288 GB of HBM the
+        caption trainer can keep the dataset resident and index batches on the GPU."""
+        prefix = self.prefixes[self.caption2embedding]
+        if self.normalize_prefix:
+            prefix = prefix.float()
+            prefix = prefix / prefix.norm(2, -1, keepdim=True)
+        out = (self.tokens, self.masks, prefix, self.attributes)
+        return tuple(t.to(device) for t in out) if device is not None else out

@@ -213,6 +213,21 @@ class GPT2LMHeadModel(_Holder):
         self.transformer = _GPT2Transformer(geo)
         self.lm_head = _LMHead(self.transformer.wte)
         self._owner = None
+        # Checkpoint wire format: every reference script strict-loads a full ClipCaptionModel state_dict
+        # (train.py:320, test.py:337/598, predict.py:61).  transformers 4.x releases that still ship `AdamW` (train.py:6)
+        # register GPT2Attention's causal-mask buffers as persistent, so such files carry
+        # `<prefix>transformer.h.N.attn.bias` / `.attn.masked_bias`; newer ones omit them and may omit the tied
+        # `lm_head.weight`.  Both load unchanged: the buffers are dropped (the mask is applied inside the attention kernel),
+        # the tied head is filled from wte.
+        self._register_load_state_dict_pre_hook(self._normalise_hf_gpt2_keys)
+
+    @staticmethod
+    def _normalise_hf_gpt2_keys(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for k in [k for k in state_dict if k.startswith(prefix) and k.endswith((".attn.bias", ".attn.masked_bias"))]:
+            del state_dict[k]
+        wte = prefix + "transformer.wte.weight"
+        if wte in state_dict:
+            state_dict.setdefault(prefix + "lm_head.weight", state_dict[wte])
 
     @classmethod
     def from_pretrained(cls, name: str, **kw) -> "GPT2LMHeadModel":
@@ -223,10 +238,7 @@ class GPT2LMHeadModel(_Holder):
         m = cls(geo)
         path = name if os.path.isfile(name) else os.path.join(name, "pytorch_model.bin")
         if os.path.isfile(path):
-            sd = torch.load(path, map_location="cpu", weights_only=True)
-            sd = {k: v for k, v in sd.items() if not k.endswith((".attn.bias", ".attn.masked_bias"))}
-            sd.setdefault("lm_head.weight", sd["transformer.wte.weight"])
-            m.load_state_dict(sd)
+            m.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))   # (HF buffer keys: pre-hook above)
         else:
             warnings.warn(f"GPT2LMHeadModel.from_pretrained({name!r}): no local weights and no network - seeded synthetic init")
             full = init_caption_state_dict(geo, 567)
@@ -470,13 +482,52 @@ class ClipCaptionModel(nn.Module):
         ops.gemm_bf16(h1, ar.b["clip_project.model.2.weight"], bias=ar.params["clip_project.model.2.bias"].data, out_f32=out)
         return out, (pb, h1) if train else None
 
+    def _mlp_mapper_backward(self, msave, dproj: torch.Tensor, ld: int, A):
+        """MLP mapper backward (Linear - Tanh - Linear, train.py:110-123).  dproj: 16-bit [B, n_out] gradient of the mapper
+        output with row stride `ld` (a column slice of the GPT-2 input gradient, or a dense matrix)."""
+        ar = self._arena
+        g, sc = ar.g, self._stack.scratch
+        pb, h1 = msave
+        B = pb.shape[0]
+        n_in, n_hid, n_out = self.clip_project.sizes
+        w0, b0, w2, b2 = ("clip_project.model.0.weight", "clip_project.model.0.bias", "clip_project.model.2.weight",
+                          "clip_project.model.2.bias")
+        ops.gemm_bf16(dproj, h1, a_kcontig=False, b_kcontig=False, residual=g[w2] if A(w2) else None, out_f32=g[w2])
+        ops.colsum(dproj, g[b2], sc.floats(ops.colsum_ws_floats(B, n_out)), R=B, C=n_out, ld=ld, accumulate=A(b2))
+        dh1 = torch.empty(B, n_hid, device=dproj.device, dtype=self.compute_dtype)
+        ops.gemm_bf16(dproj, ar.b[w2], b_kcontig=False, act=ops.ACT_DTANH, aux=h1, out_bf16=dh1)
+        ops.gemm_bf16(dh1, pb, a_kcontig=False, b_kcontig=False, residual=g[w0] if A(w0) else None, out_f32=g[w0])
+        ops.colsum(dh1, g[b0], sc.floats(ops.colsum_ws_floats(B, n_hid)), R=B, C=n_hid, ld=n_hid, accumulate=A(b0))
+
+    def _mapper_only_backward(self, msave, dout: torch.Tensor):
+        """gradient of `clip_project(prefix)` alone: dout fp32 [B, P*D] (MLP) / [B, P, D] (TransformerMapper)"""
+        ar = self._arena
+        acc = ar.begin_backward()
+        g = ar.g
+
+        def A(name):
+            return acc[id(g[name])]
+
+        B, P, D = dout.shape[0], self.prefix_length, self.model_embedding_size
+        d32 = dout.detach().float().contiguous().view(B, P * D)
+        d16 = torch.empty(B, P * D, device=dout.device, dtype=self.compute_dtype)
+        ops.cast_f32_to_bf16(d32, d16)
+        if self._mstack is not None:
+            self._tmapper_backward(msave, d32.view(B * P, D), d16.view(B * P, D), B, P, acc, A)
+        else:
+            self._mlp_mapper_backward(msave, d16, P * D, A)
+        ar.publish_grads([n for n in ar.names if n.startswith("clip_project.") and ar.params[n].requires_grad])
+
     def _mapper_only(self, prefix: torch.Tensor) -> torch.Tensor:
-        """`model.clip_project(prefix)` as the inference scripts call it (test.py:540, application.py:104)."""
+        """`model.clip_project(prefix)` as the inference scripts call it (test.py:540, application.py:104); differentiable
+        with respect to the mapper's parameters (the prefix embedding is data)."""
         self._ensure_runtime()
         self._arena.refresh_shadows()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.clip_project.parameters()):
-            raise NotImplementedError("differentiate through ClipCaptionModel.forward / caption_loss, not clip_project alone")
-        out = self._mapper_forward(prefix, False)[0]
+        names = [n for n in self._arena.names if n.startswith("clip_project.")]
+        if torch.is_grad_enabled() and any(self._arena.params[n].requires_grad for n in names):
+            out = _MapperOnly.apply(self, prefix, *[self._arena.params[n] for n in names])
+        else:
+            out = self._mapper_forward(prefix, False)[0]
         if isinstance(self.clip_project, TransformerMapper):          # train.py:247 returns [B, prefix_length, D]
             out = out.view(-1, self.prefix_length, self.model_embedding_size)
         return out
@@ -653,17 +704,7 @@ class ClipCaptionModel(nn.Module):
             if p["clip_project.linear.weight"].requires_grad:
                 self._tmapper_backward(c["msave"], dx, dxb, B, S, acc, A)
         elif p["clip_project.model.2.weight"].requires_grad:
-            pb, h1 = c["msave"]
-            n_in, n_hid, n_out = self.clip_project.sizes
-            dproj = dxb.view(B, S * D)[:, :P * D]
-            w0, b0, w2, b2 = ("clip_project.model.0.weight", "clip_project.model.0.bias", "clip_project.model.2.weight",
-                              "clip_project.model.2.bias")
-            ops.gemm_bf16(dproj, h1, a_kcontig=False, b_kcontig=False, residual=g[w2] if A(w2) else None, out_f32=g[w2])
-            ops.colsum(dproj, g[b2], sc.floats(ops.colsum_ws_floats(B, n_out)), R=B, C=n_out, ld=S * D, accumulate=A(b2))
-            dh1 = torch.empty(B, n_hid, device=dev, dtype=self.compute_dtype)
-            ops.gemm_bf16(dproj, ar.b[w2], b_kcontig=False, act=ops.ACT_DTANH, aux=h1, out_bf16=dh1)
-            ops.gemm_bf16(dh1, pb, a_kcontig=False, b_kcontig=False, residual=g[w0] if A(w0) else None, out_f32=g[w0])
-            ops.colsum(dh1, g[b0], sc.floats(ops.colsum_ws_floats(B, n_hid)), R=B, C=n_hid, ld=n_hid, accumulate=A(b0))
+            self._mlp_mapper_backward(c["msave"], dxb.view(B, S * D)[:, :P * D], S * D, A)
         ar.publish_grads([n for n in ar.names if ar.params[n].requires_grad])
 
 
@@ -682,6 +723,20 @@ class ClipCaptionPrefix(ClipCaptionModel):
         super().train(mode)
         self.model.eval()
         return self
+
+
+class _MapperOnly(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: "ClipCaptionModel", prefix, *params):
+        out, msave = model._mapper_forward(prefix, True)
+        ctx.model, ctx.msave, ctx.n = model, msave, len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.model._mapper_only_backward(ctx.msave, dout)
+        ctx.msave = None
+        return (None, None) + (None,) * ctx.n
 
 
 class _CaptionLogits(torch.autograd.Function):

@@ -42,10 +42,12 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 }
 
 template <typename DT>
-__global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict__ logits, long ld, int R, int C,
+// `dlogits` may alias `logits` (clip/loss.py overwrites the logits with their gradient in place), so neither carries
+// __restrict__: every element is read by the lane that later writes it, and the label's logit is taken before any store.
+__global__ __launch_bounds__(256) void xent_rows_kernel(const float* logits, long ld, int R, int C,
                                                         const int* __restrict__ labels, int ignore_index,
                                                         float grad_scale, float* __restrict__ loss_row,
-                                                        int* __restrict__ pred, DT* __restrict__ dlogits, long ldd,
+                                                        int* __restrict__ pred, DT* dlogits, long ldd,
                                                         float* __restrict__ rowdot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
@@ -70,8 +72,9 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
     }
     const float lse = m + __logf(s);
     const bool ignored = label == ignore_index || label < 0 || label >= C;
+    const float at_label = ignored ? 0.f : row[label];
     if (lane == 0) {
-      if (loss_row) loss_row[r] = ignored ? 0.f : lse - row[label];
+      if (loss_row) loss_row[r] = ignored ? 0.f : lse - at_label;
       if (pred) pred[r] = arg;
     }
     if (dlogits) {

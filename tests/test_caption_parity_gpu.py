@@ -21,9 +21,9 @@ def sample(t, keep=4096):
     return f[::k].clone()
 
 
-def _setup():
+def _setup(fix="caption_test_tiny.pt"):
     from clip_caption import ClipCaptionModel, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch
-    g = torch.load(os.path.join(GOLD, "caption_test_tiny.pt"), weights_only=True)
+    g = torch.load(os.path.join(GOLD, fix), weights_only=True)
     geo = GPT2_MODELS[g["model"]]
     model = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
     model.load_state_dict(init_caption_state_dict(geo, g["seed"]))
@@ -73,6 +73,72 @@ def test_caption_loss_and_grads_fused():
         if k == "model.lm_head.weight":
             continue
         assert abs(params[k].grad.norm().item() - nrm.item()) <= 0.04 * nrm.item() + 1e-7, k
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_caption_real_geometry_matches_golden(half):
+    """BASELINE configs[3] at its real geometry: GPT-2-small (V = 21128, 12 layers, 12 heads), MLP mapper 512 -> 7680 ->
+    15360, P = A = 20, Lc = 40 (S = 80), B = 2 (CLIP_prefix_caption/train.py:277-279, 354-357) against the oracle: mapper
+    output, the logits slice the loss reads, the loss, 7 sampled gradients and every gradient norm."""
+    g, geo, model, tokens, mask, prefix, attribute = _setup("caption_gpt2_base_chinese.pt")
+    assert (geo.vocab_size, geo.n_layer, geo.n_embd, geo.prefix_length, geo.attribute_length) == (21128, 12, 768, 20, 20)
+    assert model.clip_project.model[0].weight.shape == (7680, 512) and model.clip_project.model[2].weight.shape == (15360, 7680)
+    if half:
+        model.half()
+    tol = dict(logit=1e-2, feat=1.5e-3, loss=1e-3, grad=1.2e-2, norm=0.01) if half else \
+        dict(logit=0.06, feat=1.2e-2, loss=5e-3, grad=6e-2, norm=0.04)
+    P, A = geo.prefix_length, geo.attribute_length
+    with torch.no_grad():
+        out = model(tokens, prefix, attribute, mask)
+        mapped = model.clip_project(prefix)
+    assert out.logits.shape == (g["b"], P + A + g["lc"], geo.vocab_size)
+    sl = out.logits[:, P + A - 1:-1]
+    assert (sample(sl, 8192).cpu() - g["logits_slice"]).abs().max() < tol["logit"]
+    assert rel(sample(mapped, 8192), g["mapper_out"]) < tol["feat"]
+    loss = model.caption_loss(tokens, prefix, attribute, mask)
+    loss.backward()
+    assert abs(loss.item() - g["loss"].item()) < tol["loss"]
+    params = dict(model.named_parameters())
+    for k, ref in g["grads"].items():
+        assert rel(sample(params[k].grad), ref) < tol["grad"], (k, rel(sample(params[k].grad), ref))
+    for k, nrm in g["grad_norms"].items():
+        if k == "model.lm_head.weight":
+            continue
+        assert abs(params[k].grad.norm().item() - nrm.item()) <= tol["norm"] * nrm.item() + 1e-7, k
+
+
+def test_caption_bs256_properties():
+    """BASELINE configs[3] at its batch (bs 256, S = 80, real geometry): batch independence, key padding, and the fused LM
+    loss against torch's cross_entropy on the materialised logits slice (train.py:354-357)."""
+    from clip_caption import ClipCaptionModel, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch
+    geo = GPT2_MODELS["ckiplab/gpt2-base-chinese"]
+    model = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+    model.load_state_dict(init_caption_state_dict(geo, 41))
+    model = model.cuda().train()
+    B, Lc = 256, 40
+    tokens, mask, prefix, attribute = [t.cuda() for t in synthetic_caption_batch(B, geo, Lc, 42)]
+    P, A = geo.prefix_length, geo.attribute_length
+    with torch.no_grad():
+        full = model(tokens, prefix, attribute, mask).logits
+        part = model(tokens[100:104], prefix[100:104], attribute[100:104], mask[100:104]).logits
+        assert torch.equal(part, full[100:104])                                   # a sample does not see its batch
+        m2 = mask.clone(); m2[:, -5:] = 0
+        masked = model(tokens, prefix, attribute, m2).logits
+        assert torch.equal(masked[:, :-5], full[:, :-5]) and not torch.equal(masked[:, -1], full[:, -1])
+    assert torch.isfinite(full).all()
+    loss = model.caption_loss(tokens, prefix, attribute, mask)
+    sl = full[:, P + A - 1:-1].float()
+    ref = torch.nn.functional.cross_entropy(sl.reshape(-1, sl.shape[-1]).double(), tokens.flatten(), ignore_index=0)
+    assert abs(loss.item() - ref.item()) < 2e-4, (loss.item(), ref.item())
+    loss.backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+    # torch's CE on the materialised slice drives the same kernels' backward (the reference loop's form)
+    model.zero_grad(set_to_none=True)
+    out = model(tokens, prefix, attribute, mask).logits[:, P + A - 1:-1]
+    torch.nn.functional.cross_entropy(out.reshape(-1, out.shape[-1]), tokens.flatten(), ignore_index=0).backward()
+    worst = max((rel(p.grad, g1[k]), k) for k, p in model.named_parameters())
+    assert worst[0] < 2e-2, worst
 
 
 def test_caption_reference_loop_with_torch_ce():
@@ -178,3 +244,90 @@ def test_transformer_mapper_reference_shape_runs():
         assert all(p.grad.abs().max() > 0 for p in model.clip_project.parameters())
         opt.step()
     assert losses[-1] < losses[0], losses
+
+
+# ---- against fixtures produced by RUNNING the reference's own classes (tests/golden/make_reference_fixtures.py) ----------
+def _ref_fixture(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=True)
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("fix,name", [("ref_mlp_mapper_tiny.pt", "test-tiny"), ("ref_mlp_mapper_real.pt", "ckiplab/gpt2-base-chinese")])
+def test_mlp_mapper_matches_reference_class_output(fix, name, half):
+    """`clip_project` (MLP, train.py:110-123; real size 512 -> 7680 -> 15360) on the HIP path against what the reference's
+    own MLP class computed from the same seeded weights: output and the gradients of sum(y * w)."""
+    from clip_caption import ClipCaptionPrefix, GPT2_MODELS, init_caption_state_dict
+    fx = _ref_fixture(fix)
+    geo = GPT2_MODELS[name]
+    model = ClipCaptionPrefix(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+    model.load_state_dict(init_caption_state_dict(geo, fx["seed"]))
+    model = model.cuda().train()
+    if half:
+        model.half()
+    y = model.clip_project(fx["prefix"].cuda())
+    assert list(y.shape) == fx["out_shape"].tolist()
+    tol, gtol = (1.5e-3, 1.2e-2) if half else (1.2e-2, 6e-2)
+    assert rel(sample(y, 8192), fx["out"]) < tol, rel(sample(y, 8192), fx["out"])
+    w = (torch.randn(y.shape, generator=torch.Generator().manual_seed(fx["w_seed"])) / y.numel() ** 0.5).cuda()
+    (y * w).sum().backward()
+    params = dict(model.named_parameters())
+    for k, ref in fx["grads"].items():
+        assert rel(sample(params[k].grad), ref) < gtol, (k, rel(sample(params[k].grad), ref))
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("fix,name", [("ref_tmapper_tiny.pt", "test-tiny"), ("ref_tmapper_real.pt", "ckiplab/gpt2-base-chinese")])
+def test_transformer_mapper_matches_reference_class_output(fix, name, half):
+    """`--mapping_type transformer` (train.py:126-248; real size: 8 layers, 8 heads x 96, 40 tokens) against the reference's
+    own TransformerMapper class on the same seeded weights."""
+    from clip_caption import ClipCaptionPrefix, GPT2_MODELS, MappingType, init_transformer_mapper_state_dict
+    fx = _ref_fixture(fix)
+    geo = GPT2_MODELS[name]
+    model = ClipCaptionPrefix(geo.prefix_length, clip_length=fx["clip_length"], prefix_size=geo.prefix_size,
+                              num_layers=fx["num_layers"], mapping_type=MappingType.Transformer, gpt2_type=geo)
+    sd = init_transformer_mapper_state_dict(geo, fx["clip_length"], fx["num_layers"], fx["seed"])
+    model.clip_project.load_state_dict({k[len("clip_project."):]: v for k, v in sd.items()})
+    model = model.cuda().train()
+    if half:
+        model.half()
+    y = model.clip_project(fx["prefix"].cuda())
+    assert y.shape == (fx["b"], geo.prefix_length, geo.n_embd)
+    tol, gtol, ntol = (2e-3, 1.5e-2, 0.01) if half else (1.5e-2, 6e-2, 0.04)
+    assert rel(sample(y, 8192), fx["out"]) < tol, rel(sample(y, 8192), fx["out"])
+    w = (torch.randn(y.shape, generator=torch.Generator().manual_seed(fx["w_seed"])) / y.numel() ** 0.5).cuda()
+    (y * w).sum().backward()
+    params = dict(model.named_parameters())
+    for k, ref in fx["grads"].items():
+        assert rel(sample(params[k].grad, 2048), ref) < gtol, (k, rel(sample(params[k].grad, 2048), ref))
+    for k, nrm in fx["grad_norms"].items():
+        assert abs(params[k].grad.norm().item() - nrm.item()) <= ntol * nrm.item() + 1e-7, k
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("fix", ["ref_caption_forward_tiny.pt", "ref_caption_forward_real.pt"])
+def test_caption_forward_matches_reference_forward(fix, half):
+    """ClipCaptionModel.forward + the train.py:356-357 loss as the reference's own code computed them (its MLP class + the local
+    transformers GPT-2, same seeded weights): logits slice, loss, sampled gradients, gradient norms."""
+    from clip_caption import ClipCaptionModel, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch
+    fx = _ref_fixture(fix)
+    geo = GPT2_MODELS[fx["model"]]
+    model = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+    model.load_state_dict(init_caption_state_dict(geo, fx["seed"]))
+    model = model.cuda().train()
+    if half:
+        model.half()
+    tokens, mask, prefix, attribute = [t.cuda() for t in synthetic_caption_batch(fx["b"], geo, fx["lc"], fx["seed"] + 1)]
+    P, A = geo.prefix_length, geo.attribute_length
+    outputs = model(tokens, prefix, attribute, mask)
+    logits = outputs.logits[:, P + A - 1:-1]
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tokens.flatten(), ignore_index=0)
+    loss.backward()
+    t = dict(logit=1e-2, loss=1e-3, grad=1.2e-2, norm=0.01) if half else dict(logit=0.06, loss=5e-3, grad=6e-2, norm=0.04)
+    assert (sample(logits, 8192).cpu() - fx["logits_slice"]).abs().max() < t["logit"]
+    assert abs(loss.item() - fx["loss"].item()) < t["loss"]
+    params = dict(model.named_parameters())
+    for k, ref in fx["grads"].items():
+        assert rel(sample(params[k].grad), ref) < t["grad"], (k, rel(sample(params[k].grad), ref))
+    for k, nrm in fx["grad_norms"].items():
+        if k in params and params[k].grad is not None and k != "model.lm_head.weight":
+            assert abs(params[k].grad.norm().item() - nrm.item()) <= t["norm"] * nrm.item() + 1e-7, k

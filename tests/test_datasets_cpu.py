@@ -90,3 +90,30 @@ def test_clip_coco_dataset_padding_mask_and_roundtrip(tmp_path):
     assert torch.equal(prefix, emb[1])
     ds_n = ClipCocoDataset(p, 20, 8, tokenizer=_CharTok(), normalize_prefix=True, write_tokens_cache=False)
     assert abs(ds_n[0][2].norm().item() - 1.0) < 1e-6
+
+
+def test_clip_coco_dataset_matches_reference_pad_tokens_fixture():
+    """tests/golden/ref_pad_tokens.pt was produced by running the reference's own ClipCocoDataset.pad_tokens / __getitem__
+    (CLIP_prefix_caption/train.py:32-63) on hand-made token lists (tests/golden/make_reference_fixtures.py): captions shorter
+    than / equal to / longer than max_seq_len, attributes on both sides of attribute_length, one negative id."""
+    from clip_caption.data import ClipCocoDataset
+    fx = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_pad_tokens.pt"), weights_only=True)
+    for key, normalize in (("plain", False), ("normalized", True)):
+        ds = ClipCocoDataset.from_token_lists(fx["captions_tokens"], fx["attributes_tokens"], fx["caption2embedding"], fx["prefixes"],
+                                              fx["prefix_length"], fx["attribute_length"], normalize, max_seq_len=fx["max_seq_len"])
+        assert len(ds) == len(fx["captions_tokens"])
+        for epoch in range(2):                              # the dense layout answers every epoch like the reference's FIRST visit
+            for i, (tokens, mask, prefix, attribute) in enumerate(fx["items"][key]["first"]):
+                t, m, p, a = ds[i]
+                assert torch.equal(t, tokens) and torch.equal(m, mask) and torch.equal(a, attribute), i
+                assert torch.allclose(p, prefix, rtol=0, atol=0 if not normalize else 1e-7), i
+                pt, pa, pm = ds.pad_tokens(i)
+                assert torch.equal(pt, tokens) and torch.equal(pa, attribute) and torch.equal(pm, mask)
+        # the one documented difference: the reference zeroes a negative id inside its cache, so its second visit of item 2
+        # reports an all-ones mask; every other item is identical on both visits
+        second = fx["items"][key]["second"]
+        diff = [i for i in range(len(ds)) if not torch.equal(second[i][1], ds[i][1])]
+        assert diff == [2] and second[2][1].min() == 1 and ds[2][1].min() == 0
+        tk, mk, pf, at = ds.tensors()
+        assert tk.shape == (len(ds), fx["max_seq_len"]) and mk.shape[1] == fx["prefix_length"] + fx["attribute_length"] + fx["max_seq_len"]
+        assert torch.allclose(pf[3], ds[3][2])

@@ -139,3 +139,26 @@ def test_linear_schedule_and_bucket_logic():
     # parameters are views of one flat buffer: an in-place change of the flat buffer is visible in the module
     ar.flat.add_(1.0)
     assert torch.equal(m.logit_scale.detach(), ar.flat[ar.offsets["logit_scale"]].reshape(()))
+
+
+def test_caption_checkpoint_with_hf_attention_buffers_loads_strict():
+    """A ClipCaptionModel state_dict as older transformers 4.x writes it (persistent `attn.bias` / `attn.masked_bias`
+    causal-mask buffers, CLIP_prefix_caption/train.py:320 strict load) and one without the tied lm_head both load."""
+    from clip_caption import ClipCaptionModel
+    from clip_caption.weights import GPT2_MODELS, init_caption_state_dict
+    geo = GPT2_MODELS["test-tiny"]
+    sd = init_caption_state_dict(geo, 5)
+    old = dict(sd)
+    for i in range(geo.n_layer):
+        old[f"model.transformer.h.{i}.attn.bias"] = torch.tril(torch.ones(geo.n_positions, geo.n_positions)).view(1, 1, geo.n_positions, -1)
+        old[f"model.transformer.h.{i}.attn.masked_bias"] = torch.tensor(-1e4)
+    new = {k: v for k, v in sd.items() if k != "model.lm_head.weight"}
+    for variant in (old, new, sd):
+        m = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+        res = m.load_state_dict(variant)                    # strict=True
+        assert not res.missing_keys and not res.unexpected_keys
+        got = m.state_dict()
+        assert set(got) == set(sd)
+        for k in sd:
+            assert torch.equal(got[k].cpu(), sd[k]), k
+    assert len(old) == len(sd) + 2 * geo.n_layer            # the caller's dict is left untouched

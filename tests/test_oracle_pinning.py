@@ -135,3 +135,79 @@ def test_hf_adamw_restatement_first_steps():
     step = 1e-2 * (1 - 0.999) ** 0.5 / (1 - 0.9)
     ref = torch.tensor([1.0, -2.0, 0.5]) - step * m / (v.sqrt() + 1e-6)
     assert torch.allclose(p["w"], ref, atol=1e-7)
+
+
+# ---- 3. against fixtures produced by RUNNING the reference's own in-tree classes (tests/golden/make_reference_fixtures.py):
+#         MLP / TransformerMapper (CLIP_prefix_caption/train.py:110-248) and ClipCaptionModel.forward (train.py:256-269) ----
+def _sample(t, keep=8192):
+    f = t.detach().flatten()
+    k = max(1, -(-f.numel() // keep))
+    return f[::k].clone()
+
+
+@pytest.mark.parametrize("fix,name", [("ref_mlp_mapper_tiny.pt", "test-tiny"), ("ref_mlp_mapper_real.pt", "ckiplab/gpt2-base-chinese")])
+def test_mlp_mapper_oracle_matches_reference_class(fix, name):
+    from clip_caption.weights import init_caption_state_dict as init
+    fx = torch.load(os.path.join(GOLD, fix), weights_only=True)
+    geo = GPT2_MODELS[name]
+    sd = {k: v.clone().requires_grad_(True) for k, v in init(geo, fx["seed"]).items() if k.startswith("clip_project.")}
+    y = CO.mlp_mapper(sd, fx["prefix"])
+    assert list(y.shape) == fx["out_shape"].tolist()
+    assert rel(_sample(y), fx["out"]) < 1e-5
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(fx["w_seed"])) / y.numel() ** 0.5
+    (y * w).sum().backward()
+    for k, ref in fx["grads"].items():
+        assert rel(_sample(sd[k].grad, 4096), ref) < 1e-4, k
+
+
+@pytest.mark.parametrize("fix,name", [("ref_tmapper_tiny.pt", "test-tiny"), ("ref_tmapper_real.pt", "ckiplab/gpt2-base-chinese")])
+def test_transformer_mapper_oracle_matches_reference_class(fix, name):
+    from clip_caption.weights import init_transformer_mapper_state_dict as init
+    fx = torch.load(os.path.join(GOLD, fix), weights_only=True)
+    geo = GPT2_MODELS[name]
+    sd = {k: v.clone().requires_grad_(True) for k, v in init(geo, fx["clip_length"], fx["num_layers"], fx["seed"]).items()}
+    y = CO.transformer_mapper(sd, fx["prefix"], fx["clip_length"])
+    assert y.shape == (fx["b"], geo.prefix_length, geo.n_embd)
+    assert rel(_sample(y), fx["out"]) < 1e-5
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(fx["w_seed"])) / y.numel() ** 0.5
+    (y * w).sum().backward()
+    for k, ref in fx["grads"].items():
+        assert rel(_sample(sd[k].grad, 2048), ref) < 1e-4, k
+    for k, nrm in fx["grad_norms"].items():
+        assert abs(sd[k].grad.norm().item() - nrm.item()) <= 1e-4 * nrm.item() + 1e-9, k
+
+
+@pytest.mark.parametrize("fix", ["ref_caption_forward_tiny.pt", "ref_caption_forward_real.pt"])
+def test_caption_oracle_matches_reference_forward(fix):
+    """The reference's ClipCaptionModel.forward + train.py:356-357 loss, run on its MLP class and the local transformers GPT-2."""
+    fx = torch.load(os.path.join(GOLD, fix), weights_only=True)
+    geo = GPT2_MODELS[fx["model"]]
+    sd = init_caption_state_dict(geo, fx["seed"])
+    tokens, mask, prefix, attribute = synthetic_caption_batch(fx["b"], geo, fx["lc"], fx["seed"] + 1)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "model.lm_head.weight"}
+    sdg["model.lm_head.weight"] = sdg["model.transformer.wte.weight"]
+    logits = CO.caption_forward(sdg, tokens, prefix, attribute, mask, geo.prefix_length, geo.n_head)
+    loss = CO.caption_loss(logits, tokens, geo.prefix_length, geo.attribute_length)
+    loss.backward()
+    P, A = geo.prefix_length, geo.attribute_length
+    assert rel(_sample(logits[:, P + A - 1:-1]), fx["logits_slice"]) < 1e-5
+    assert abs(loss.item() - fx["loss"].item()) < 1e-5
+    for k, ref in fx["grads"].items():
+        assert rel(_sample(sdg[k].grad, 4096), ref) < 2e-4, (k, rel(_sample(sdg[k].grad, 4096), ref))
+    for k, nrm in fx["grad_norms"].items():
+        if k in sdg and sdg[k].grad is not None:
+            assert abs(sdg[k].grad.norm().item() - nrm.item()) <= 2e-4 * nrm.item() + 1e-9, k
+
+
+def test_golden_vit_b32_gradients_reproduce():
+    """the round-2 ViT-B/32 gradient golden (BASELINE configs[1] geometry) is what the oracle computes from the seed"""
+    g = torch.load(os.path.join(GOLD, "clip_vit_b32.pt"), weights_only=True)
+    geo = MODELS[g["model"]]
+    sd = init_state_dict(geo, g["seed"])
+    img = synthetic_images(g["n"], geo, g["seed"] + 1)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, _ = O.contrastive_loss(*O.clip_forward(sdg, img, g["text"]))
+    loss.backward()
+    assert abs(loss.item() - g["loss"].item()) < 1e-5
+    for k, ref in g["grads"].items():
+        assert rel(_sample(sdg[k].grad, 4096), ref) < 1e-4, k
