@@ -19,7 +19,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                  every launch in the timed region (2*M*N*K) / their summed durations (HIP events on the launch
                  stream), against the 2.5 PFLOP/s dense bf16 MFMA peak.
   cpu_baseline - the CPU oracle (kind "port": the reference's `clip` package is absent) timed
-                 on the host cores for the same step on a bounded batch.
+                 on the host cores, SURVEY.md 8d's procedure (bs 64, 3 warm-up + 5 timed, median): the train step and,
+                 beside it, the forward-only encode+logits figure.
+and, in the default (train, one GPU) run, three extra objects timed after the headline steps: `encode_image`
+(images/s + fraction of the bf16 MFMA peak - BASELINE.md's 40 % target), `forward_only`, `parity_mode` (the same step
+with fp16 operands).  `roofline.traffic` / `mfma_busy` are REPLAYED from committed rocprofv3 --pmc summaries and only
+when those were taken on the same GEMM kernel sources (see attach_replayed_pmc).
 """
 from __future__ import annotations
 
@@ -68,38 +73,58 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(mode: str, budget_s: float = 12.0):
-    """Oracle step on the host cores: bounded sample (batch 32, ~10-20 s of CPU work), median iteration."""
+def cpu_baseline(mode: str, bs: int = 64):
+    """The CPU oracle on the host cores, SURVEY.md 8d's procedure: bs = 64, 3 warm-up + 5 timed iterations, median.
+    mode "train": the fwd+bwd step (value) plus the forward-only `encode_image + encode_text + logits` figure beside it
+    (the metric's own wording); "fwd": forward only; "image": encode_image only, in images/s."""
     from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
     from oracle import clip_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     geo = MODELS["ViT-B/32"]
-    bs = 32
     sd = init_state_dict(geo, 567)
     img, txt = synthetic_images(bs, geo, 568), synthetic_text(bs, geo, 569)
-    times = []
-    t_all = time.time()
-    for it in range(12):
-        t0 = time.time()
-        if mode == "train":
-            sdg = {k: v.requires_grad_(True) for k, v in sd.items()}
-            li, lt = O.clip_forward(sdg, img, txt)
-            loss, _ = O.contrastive_loss(li, lt)
-            loss.backward()
-            for v in sdg.values():
-                v.grad = None
-        else:
-            with torch.no_grad():
-                O.clip_forward(sd, img, txt)
-        times.append(time.time() - t0)
-        log(f"cpu baseline iteration {it}: {times[-1]:.2f}s")
-        if time.time() - t_all > budget_s and it >= 2:
-            break
-    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
-    return dict(value=bs / t, unit="pairs/s", cores=cores, kind="port",
-                sample=f"oracle/clip_oracle.py fp32 {mode} step (fwd{'+bwd' if mode == 'train' else ''}), batch {bs}, "
-                       f"median of {len(times) - 1 or 1} iterations after 1 warm-up, torch CPU {cores} threads")
+
+    def timed(fn, what, warm=3, reps=5, budget_s=22.0):
+        times, t_all = [], time.time()
+        for it in range(warm + reps):
+            t0 = time.time()
+            fn()
+            times.append(time.time() - t0)
+            log(f"cpu baseline {what} iteration {it}: {times[-1]:.2f}s")
+            if time.time() - t_all > budget_s and len(times) > warm:      # a slow host: keep the run bounded, say so below
+                break
+        kept = times[warm:] if len(times) > warm else times[-1:]
+        return sorted(kept)[len(kept) // 2], len(kept)
+
+    def fwd():
+        with torch.no_grad():
+            O.clip_forward(sd, img, txt)
+
+    def image_only():
+        with torch.no_grad():
+            O.encode_image(sd, img)
+
+    def train():
+        sdg = {k: v.requires_grad_(True) for k, v in sd.items()}
+        loss, _ = O.contrastive_loss(*O.clip_forward(sdg, img, txt))
+        loss.backward()
+        for v in sdg.values():
+            v.grad = None
+
+    where = f"oracle/clip_oracle.py fp32, batch {bs}, torch CPU {cores} threads, median of {{n}} timed iterations after 3 warm-up"
+    if mode == "image":
+        t, n = timed(image_only, "encode_image")
+        return dict(value=round(bs / t, 2), unit="images/s", cores=cores, kind="port", sample="encode_image only; " + where.format(n=n))
+    tf, nf = timed(fwd, "forward")
+    fwd_obj = dict(value=round(bs / tf, 2), unit="pairs/s", sample="encode_image + encode_text + logits (forward only); " + where.format(n=nf))
+    if mode != "train":
+        return dict(cores=cores, kind="port", **fwd_obj)
+    for v in sd.values():
+        v.requires_grad_(False)
+    tt, nt = timed(train, "train step")
+    return dict(value=round(bs / tt, 2), unit="pairs/s", cores=cores, kind="port",
+                sample="contrastive step forward + backward (no optimiser); " + where.format(n=nt), forward=fwd_obj)
 
 
 def gemm_roofline(ev, nprof, traffic=None, traffic_src=None):
@@ -119,6 +144,32 @@ def gemm_roofline(ev, nprof, traffic=None, traffic_src=None):
                 launches_per_step=len(ev) // nprof, gemm_ms_per_step=round(tot_ms / nprof, 3),
                 by_layout={k: dict(tflops=round(fl / (t * 1e-3) / 1e12, 1), ms_per_step=round(t / nprof, 3), launches=n // nprof)
                            for k, (t, fl, n) in by.items()})
+
+
+def attach_replayed_pmc(roof, args, B, world, src_hash):
+    """PMC counters cannot be read from inside the process.  `traffic` (FETCH_SIZE x 2 per MI355X_MICROARCH.md + WRITE_SIZE, per
+    GEMM launch) and `mfma_busy` are therefore REPLAYED from the committed rocprofv3 --pmc summaries of this same command
+    (profiles/r02_train_bs1024_*_pmc.json) and marked as such - and only when they describe what just ran: default train
+    step, ViT-B/32, bs 1024, bf16, one GPU, and the SAME GEMM kernel sources (hash recorded when the profile was taken).
+    Anything else reports null rather than a stale number."""
+    roof["traffic_replayed"] = None
+    if not (args.mode == "train" and B == 1024 and args.dtype == "bf16" and args.model == "ViT-B/32" and world == 1):
+        return
+    tp = os.path.join(ROOT, "profiles", "r02_train_bs1024_hbm_traffic_pmc.json")
+    mp = os.path.join(ROOT, "profiles", "r02_train_bs1024_mfma_busy_pmc.json")
+    try:
+        t = json.load(open(tp))
+        if t.get("kernel_source_hash") == src_hash:
+            gf = t["gemm_family"]
+            roof["traffic"] = round((gf["fetch_mb_per_launch_corrected"] + gf["write_mb_per_launch"]) * 1e6)
+            roof["traffic_replayed"] = dict(source="profiles/r02_train_bs1024_hbm_traffic_pmc.json", command=t.get("command"),
+                                            git=t.get("git"), kernel_source_hash=src_hash)
+        m = json.load(open(mp))
+        if m.get("kernel_source_hash") == src_hash:
+            roof["mfma_busy"] = m["gemm_family_mfma_busy"]
+            roof["mfma_busy_replayed"] = dict(source="profiles/r02_train_bs1024_mfma_busy_pmc.json", git=m.get("git"))
+    except (OSError, KeyError, ValueError):
+        pass
 
 
 def caption_main(args, rank, world, dev, B, cdt):
@@ -219,6 +270,61 @@ def caption_cpu_baseline(geo, Lc, budget_s: float = 12.0):
                        f"torch CPU {cores} threads")
 
 
+def _time_loop(fn, warm: int, reps: int) -> float:
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def extra_legs(model, image, text, geo, B, args):
+    import clip
+    from clip import optim as coptim
+    from clip.weights import init_state_dict
+    img_fl, txt_fl = tower_flops(geo)
+    out = {}
+    model.eval()
+
+    def enc_image():
+        with torch.no_grad():
+            model.encode_image(image)
+
+    def fwd():
+        with torch.no_grad():
+            fi, ft = model.encode_image_text(image, text)
+            clip.contrastive_loss(fi, ft, model.logit_scale, None)
+
+    t = _time_loop(enc_image, 3, 20)
+    out["encode_image"] = dict(images_per_s=round(B / t, 1), ms=round(t * 1e3, 3), frac_of_bf16_peak=round(img_fl * B / t / PEAK_BF16, 4),
+                               note="encode_image alone, same model / batch / operand type as the headline step, 20 iterations")
+    t = _time_loop(fwd, 3, 20)
+    out["forward_only"] = dict(pairs_per_s=round(B / t, 1), ms=round(t * 1e3, 3),
+                               frac_of_bf16_peak=round((img_fl + txt_fl) * B / t / PEAK_BF16, 4),
+                               note="encode_image + encode_text + logits + loss, forward only, 20 iterations")
+    model.train()
+    if args.dtype == "bf16":
+        m16 = clip.build_model(init_state_dict(geo, 567), torch.float16).to(image.device).train()
+        o16 = coptim.AdamW(m16, lr=1e-5)
+
+        def step16():
+            o16.zero_grad()
+            fi, ft = m16.encode_image_text(image, text)
+            loss, stats = clip.contrastive_loss(fi, ft, m16.logit_scale, None)
+            loss.backward()
+            o16.step()
+
+        t = _time_loop(step16, 3, 6)
+        out["parity_mode"] = dict(dtype="fp16", ms_per_step=round(t * 1e3, 3), pairs_per_s=round(B / t, 1),
+                                  note="the same train step with fp16 MFMA operands (features <= 1e-3 of the fp32 oracle, bit-exact "
+                                       "argmax: tests/test_clip_parity_gpu.py); 6 iterations")
+        del m16, o16
+    return out
+
+
 def log(msg: str):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -236,6 +342,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default 1024; 256 for --mode caption)")
     ap.add_argument("--mode", choices=["train", "fwd", "image", "caption"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="train mode: skip the extra encode_image / forward-only / fp16-operand legs timed after the headline steps")
     ap.add_argument("--model", default="ViT-B/32")
     ap.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default="bf16",
                     help="MFMA operand type; fp8 = e4m3 qkv / fc projections of the image tower (inference modes only), bf16 elsewhere")
@@ -275,6 +383,7 @@ def main():
     image = torch.randn(B, 3, geo.image_resolution, geo.image_resolution, device=dev, generator=g)
     text = synthetic_text(B, geo, 567 + rank).to(dev)
     group = None
+    reducer = parallel.GradReducer(model, group)
 
     os.environ["CCLIP_TOWER_STREAMS"] = str(args.tower_streams)
 
@@ -293,8 +402,9 @@ def main():
         opt.zero_grad()
         fi, ft = encode_both()
         loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale, group)
+        reducer.begin()              # N > 1: gradient buckets are all-reduced from inside backward, block group by block group
         loss.backward()
-        opt.step(pending=parallel.allreduce_gradients_async(model, group))   # AdamW bucket i under the all-reduce of bucket i+1
+        opt.step(pending=reducer.finish())   # AdamW bucket i as soon as it is reduced, under the all-reduce of bucket i+1
         sched.step()
         return stats
 
@@ -336,22 +446,19 @@ def main():
     if rank == 0:
         ev = ops.GEMM_EVENTS
         ops.GEMM_EVENTS = None
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_train_bs1024_hbm_traffic_pmc.json")
-        if os.path.exists(tp) and args.mode == "train" and B == 1024 and args.dtype == "bf16":
-            # PMC counters cannot be read from inside the process: this is the committed rocprofv3 --pmc summary of the
-            # same command (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE), bytes per GEMM launch
-            gf = json.load(open(tp))["gemm_family"]
-            traffic = round((gf["fetch_mb_per_launch_corrected"] + gf["write_mb_per_launch"]) * 1e6)
-            traffic_src = "profiles/r01_train_bs1024_hbm_traffic_pmc.json"
-        roof = gemm_roofline(ev, nprof, traffic, traffic_src)
-        mp = os.path.join(ROOT, "profiles", "r01_train_bs1024_mfma_busy_pmc.json")
-        if os.path.exists(mp) and traffic is not None:
-            # matrix-pipe busy fraction of the GEMM family from the committed PMC pass of the same command (clock-independent)
-            roof["mfma_busy"] = json.load(open(mp))["gemm_family_mfma_busy"]
-            roof["mfma_busy_source"] = "profiles/r01_train_bs1024_mfma_busy_pmc.json"
+        roof = gemm_roofline(ev, nprof, None, None)
+        attach_replayed_pmc(roof, args, B, world, ops.kernel_source_hash())
     if world > 1:
         dist.barrier()
+
+    # ---- extra legs of the default run (one GPU, train mode): the figures BASELINE.md's targets are quoted on, timed in
+    # the driver's own run so that they are driver-observable: encode_image alone (the ">= 40 % of the bf16 MFMA roofline"
+    # target), encode+logits forward only (the metric's own wording), and the same train step with fp16 operands (the
+    # operand type that meets north_star's 1e-3 parity bar, tests/test_clip_parity_gpu.py) ----
+    extras = None
+    if args.mode == "train" and world == 1 and not args.no_extras:
+        extras = extra_legs(model, image, text, geo, B, args)
+        log("extra legs done")
 
     if rank == 0:
         pairs = B * world * args.steps
@@ -359,8 +466,10 @@ def main():
         img_fl, txt_fl = tower_flops(geo)
         step_flops = (img_fl if args.mode == "image" else (img_fl + txt_fl) * (3 if args.mode == "train" else 1)) * B
         out = {
-            "metric": (f"images/sec encode_image {args.model} bs={B}" if args.mode == "image"
-                       else "image-text pairs/sec (encode+logits) ViT-B/32 bs=1024 at 1/2/4/8 MI355X"),
+            "metric": (f"images/sec encode_image {args.model} bs={B} at {world} MI355X" if args.mode == "image"
+                       else f"image-text pairs/sec (encode+logits"
+                            f"{' forward only' if args.mode == 'fwd' else ' + backward + AdamW: the full CLIP/train.py step'}) "
+                            f"{args.model} bs={B} at {world} MI355X"),
             "value": round(value, 1), "unit": "images/s" if args.mode == "image" else "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -374,8 +483,10 @@ def main():
             "roofline": roof,
         }
         log("roofline leg done")
+        if extras is not None:
+            out.update(extras)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline("fwd" if args.mode == "image" else args.mode)
+            out["cpu_baseline"] = cpu_baseline(args.mode)
             log("cpu baseline done")
         else:
             out["cpu_baseline"] = None

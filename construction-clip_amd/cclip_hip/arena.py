@@ -48,6 +48,9 @@ class ParamArena:
                 self.b[n] = self.bflat[off:off + k].view(p.shape)
         self._stamp = None
         self.accumulating: Dict[int, bool] = {}
+        # set by clip.parallel.GradReducer: called as listener(grad_views, producer_streams) from inside the hand-written
+        # backward whenever a group of gradient slots has had its last kernel ENQUEUED (not finished: the streams say where)
+        self.grad_listener = None
 
     # ---- bf16 shadows ----
     def _current_stamp(self):
@@ -86,9 +89,31 @@ class ParamArena:
                 acc[id(gv)] = True
         return acc
 
+    def adopt_foreign_grads(self) -> int:
+        """A parameter reached through ordinary autograd edges (CLIP's `logit_scale`: the loss node returns its gradient
+        to autograd, which allocates `.grad` itself) has its gradient OUTSIDE the arena.  Everything that works on the flat
+        gradient buffer - the fused optimiser, the data-parallel all-reduce - calls this first: such gradients are copied
+        into their slots and `.grad` is re-pointed at the slot.  Returns the number adopted."""
+        n_adopted = 0
+        for n, p in self.params.items():
+            gr = p.grad
+            if gr is not None and gr.data_ptr() != self.g[n].data_ptr():
+                self.g[n].copy_(gr)
+                p.grad = self.g[n]
+                n_adopted += 1
+        return n_adopted
+
+    def notify_grads(self, grad_views, streams=()) -> None:
+        if self.grad_listener is not None:
+            self.grad_listener(grad_views, streams)
+
     def publish_grads(self, names) -> None:
         """Point .grad of the parameters whose slots were just written at the arena views."""
         for n in names:
             p = self.params[n]
             if p.requires_grad and p.grad is None:
                 p.grad = self.g[n]
+        if self.grad_listener is not None:
+            import torch as _t
+            st = [_t.cuda.current_stream()] if self.gflat.is_cuda else []
+            self.grad_listener([self.g[n] for n in names if self.params[n].requires_grad], st)

@@ -83,11 +83,107 @@ class GemmDesc(ctypes.Structure):
 # Tile-configuration autotuner.  The GEMM tile configurations (128x128, 256x128, 256x256, persistent 256x128 with a
 # streamed epilogue - forward layout / full tiles only) win on different
 # shapes (tile-count quantisation over 256 CUs, K length, epilogue weight), and a model issues ~20 distinct GEMM
-# shapes thousands of times: the first call of a new (shape, layout, epilogue, split) key times the candidates on
-# scratch outputs and caches the winner.  AUTOTUNE=False pins configuration 1.
+# shapes thousands of times.  The choice per (shape, layout, epilogue, split) key comes from a PERSISTED table:
+#   * `gemm_tune.json` next to libcclip_hip.so (committed; refreshed by tools/tune_gemm.py on a GPU box), or the file named
+#     by CCLIP_TUNE_FILE, is loaded at the first GEMM call.  It is keyed by a hash of the GEMM kernel sources: a table made
+#     for other kernels is ignored.
+#   * only a key the table does not hold is timed (trial launches on scratch outputs, GPU to itself), added to the table,
+#     and - when CCLIP_TUNE_FILE is set or CCLIP_TUNE_SAVE=1 - written back, so the next process does not tune at all.
+#   * under data parallelism rank 0's table is broadcast (`sync_tuned_table`), and a key missed later is decided by rank 0
+#     for everyone: all ranks run the same tiles, hence the same summation order.
+# With a complete table a run is launch-for-launch reproducible: no trial launches, no timing-dependent choices.
+# AUTOTUNE=False pins configuration 1.
 AUTOTUNE = True
 _TUNED = {}
 _TUNE_MIN_FLOPS = 2.0 * (1 << 29)
+_TUNE_STATE = {"loaded": False, "source_hash": None, "misses": 0, "path": None}
+
+
+def _tune_paths():
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.environ.get("CCLIP_TUNE_FILE"), os.path.join(here, "gemm_tune.json")
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the GEMM kernel sources (csrc/gemm_bf16*.hip, gemm_bf16_impl.h, cclip_common.h): the key a tuned table
+    is valid for."""
+    import hashlib, os
+    if _TUNE_STATE["source_hash"] is None:
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+        h = hashlib.sha256()
+        for f in sorted(os.listdir(csrc)):
+            if f.startswith("gemm_bf16") or f == "cclip_common.h":
+                h.update(f.encode())
+                with open(os.path.join(csrc, f), "rb") as fh:
+                    h.update(fh.read())
+        _TUNE_STATE["source_hash"] = h.hexdigest()[:16]
+    return _TUNE_STATE["source_hash"]
+
+
+def _key_str(key) -> str:
+    return "|".join(str(int(k)) if isinstance(k, bool) else str(k) for k in key)
+
+
+def load_tuned_table(path=None, force: bool = False) -> int:
+    """Load the persisted (key -> (tile_config, split_k)) table; returns the number of entries taken."""
+    import json, os
+    if _TUNE_STATE["loaded"] and not force and path is None:
+        return 0
+    _TUNE_STATE["loaded"] = True
+    env, default = _tune_paths()
+    n = 0
+    for cand in ([path] if path else [default, env]):       # the env file is read last: its entries win
+        if cand and os.path.isfile(cand):
+            try:
+                with open(cand) as f:
+                    blob = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if blob.get("kernel_source_hash") != kernel_source_hash():
+                continue                                    # made for other kernels: tune again
+            for k, v in blob.get("table", {}).items():
+                _TUNED[k] = (int(v[0]), int(v[1]))
+                n += 1
+            _TUNE_STATE["path"] = cand
+    return n
+
+
+def save_tuned_table(path=None) -> str:
+    import json, os
+    env, default = _tune_paths()
+    path = path or env or default
+    blob = {"kernel_source_hash": kernel_source_hash(),
+            "note": "GEMM tile configuration per (dtype, M, N, K, layout, epilogue, split) key; written by cclip_hip.ops",
+            "table": {k: list(v) for k, v in sorted(_TUNED.items())}}
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        json.dump(blob, f, indent=0, sort_keys=True)
+    os.replace(tmp, path)
+    return path
+
+
+def sync_tuned_table(group=None, src: int = 0) -> None:
+    """Data parallelism: every rank adopts rank `src`'s table (call once after init_process_group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    load_tuned_table()
+    box = [dict(_TUNED) if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    _TUNED.clear()
+    _TUNED.update(box[0])
+
+
+def _agree_on_choice(choice):
+    """a key tuned mid-run under DP: rank 0's measurement decides for every rank (same call sequence on all ranks)"""
+    import os
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or os.environ.get("CCLIP_TUNE_DP_SYNC", "1") == "0":
+        return choice
+    box = [choice]
+    dist.broadcast_object_list(box, src=0)
+    return tuple(box[0])
 
 
 def _launch_gemm(d) -> None:
@@ -145,7 +241,15 @@ def _autotune(d, key, outs, candidates):
             best, best_t = (cfg, sp), t
     d.out_f32, d.out_bf16, d.out_pre_bf16, d.tile_config, d.split_k, d.split_ws = saved
     d.colsum_out, d.colsum_accumulate = saved_cs
+    best = _agree_on_choice(best)
     _TUNED[key] = best
+    _TUNE_STATE["misses"] += 1
+    import os
+    if os.environ.get("CCLIP_TUNE_FILE") or os.environ.get("CCLIP_TUNE_SAVE") == "1":
+        try:
+            save_tuned_table()
+        except OSError:
+            pass
     return best
 
 
@@ -207,8 +311,11 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
     if out_f32 is not None:
         _req(out_f32, torch.float32, "out_f32")
     if tile_config == 0 and AUTOTUNE and 2.0 * M * N * K >= _TUNE_MIN_FLOPS and (outs[0].is_contiguous() or True):
-        key = (A.dtype, M, N, K, a_kcontig, b_kcontig, act, out_f32 is not None, out_bf16 is not None, out_pre is not None,
-               residual is not None, bias is not None, split_k if split_candidates is None else -1, colsum_out is not None, colsum_of_b)
+        if not _TUNE_STATE["loaded"]:
+            load_tuned_table()
+        key = _key_str((str(A.dtype).replace("torch.", ""), M, N, K, a_kcontig, b_kcontig, act, out_f32 is not None,
+                        out_bf16 is not None, out_pre is not None, residual is not None, bias is not None,
+                        split_k if split_candidates is None else -1, colsum_out is not None, colsum_of_b))
         choice = _TUNED.get(key)
         if choice is None:
             cands = split_candidates if split_candidates is not None else [(1, split_k), (2, split_k), (3, split_k), (4, split_k)]

@@ -29,10 +29,16 @@ def _world(group) -> Tuple[int, int]:
     return 0, 1
 
 
+def _collectives(group) -> bool:
+    from .parallel import collectives_active
+    return collectives_active(group)
+
+
 class _Contrastive(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fi, ft, logit_scale, group):
         rank, world = _world(group)
+        dp = _collectives(group)              # world > 1, or a forced one-rank RCCL pass (clip.parallel.collectives_active)
         dev = fi.device
         fi, ft = fi.contiguous().float(), ft.contiguous().float()
         ls = logit_scale.detach().float().reshape(1).contiguous()
@@ -46,7 +52,7 @@ class _Contrastive(torch.autograd.Function):
         inv_t = torch.empty(nloc, device=dev, dtype=torch.float32)
         ops.l2norm_fwd(fi, i_n, inv_i)
         ops.l2norm_fwd(ft, t_n, inv_t)
-        if world > 1:
+        if dp:
             gathered = torch.empty(N, 2 * E, device=dev, dtype=torch.float32)
             dist.all_gather_into_tensor(gathered, packed, group=group)
         else:
@@ -71,14 +77,14 @@ class _Contrastive(torch.autograd.Function):
         ops.reduce_dot(loss_rows.view(-1), None, out[0:1], alpha=gs)
         hit = (pred == labels).to(torch.float32)                                 # integer compare (bookkeeping)
         ops.reduce_dot(hit, None, out[1:2])
-        if world > 1:
+        if dp:
             dist.all_reduce(out, group=group)
         if need_grad:
             # d/d(normalised features): local rows + the other ranks' rows that used our features
             cross = torch.empty(N, 2 * E, device=dev, dtype=torch.float32)
             ops.gemm_f32(L_t.t(), t_n.t(), cross[:, :E], alpha_log_dev=ls)       # -> d I_all = s dL_t^T T_loc
             ops.gemm_f32(L_i.t(), i_n.t(), cross[:, E:], alpha_log_dev=ls)       # -> d T_all = s dL_i^T I_loc
-            if world > 1:
+            if dp:
                 d = torch.empty(nloc, 2 * E, device=dev, dtype=torch.float32)
                 dist.reduce_scatter_tensor(d, cross, group=group)
             else:

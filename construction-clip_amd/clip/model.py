@@ -203,6 +203,7 @@ class CLIP(nn.Module):
             txt_names=[n for n in ar.names if not n.startswith("visual.") and n != "logit_scale"],
         )
         self._rt["vis"].fp8, self._rt["txt"].fp8 = getattr(self, "_fp8_projections", (False, False))
+        self._rt["vis"].grad_hook = self._rt["txt"].grad_hook = ar.notify_grads
 
     def fp8_projections(self, enabled: bool = True, text: bool = False):
         """INFERENCE ONLY: run the LayerNorm-fed projections (qkv, fc) of the image tower - and, with text=True, of the text

@@ -36,6 +36,8 @@ class AdamW:
         """pending: [(start, end, work)] from parallel.allreduce_gradients_async - the arena is then updated range by range,
         each as soon as its all-reduce has finished (the ranges must cover the arena; same result as one pass)."""
         arena = self._state()
+        if not pending:
+            arena.adopt_foreign_grads()      # (with pending reductions the reducer adopted them before it reduced)
         g = self.param_groups[0]
         self.step_count += 1
         # parameters that never received a gradient keep a zero slot -> no update beyond decay (as HF skips them).

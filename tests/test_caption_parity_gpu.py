@@ -82,7 +82,8 @@ def test_caption_real_geometry_matches_golden(half):
     output, the logits slice the loss reads, the loss, 7 sampled gradients and every gradient norm."""
     g, geo, model, tokens, mask, prefix, attribute = _setup("caption_gpt2_base_chinese.pt")
     assert (geo.vocab_size, geo.n_layer, geo.n_embd, geo.prefix_length, geo.attribute_length) == (21128, 12, 768, 20, 20)
-    assert model.clip_project.model[0].weight.shape == (7680, 512) and model.clip_project.model[2].weight.shape == (15360, 7680)
+    sdm = model.state_dict()
+    assert sdm["clip_project.model.0.weight"].shape == (7680, 512) and sdm["clip_project.model.2.weight"].shape == (15360, 7680)
     if half:
         model.half()
     tol = dict(logit=1e-2, feat=1.5e-3, loss=1e-3, grad=1.2e-2, norm=0.01) if half else \

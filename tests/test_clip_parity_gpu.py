@@ -318,6 +318,9 @@ def test_train_step_decreases_loss_and_matches_oracle_adamw_direction():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0] - 0.05, losses
+    # logit_scale's gradient reaches it through plain autograd (outside the arena): the fused optimiser must see it too.
+    # Adam's first steps move a scalar by ~lr each: 4 steps of lr 1e-3 from ln(1/0.07)
+    assert 1e-3 < abs(model.logit_scale.item() - 2.6592600) < 5e-3, model.logit_scale.item()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     m2 = clip.build_model(sd).cuda()
     with torch.no_grad():

@@ -71,7 +71,37 @@ def _worker(rank, world, port, out_dir):
                 opt.step(grad_scale=0.5)
         res.append(a2.flat.clone())
     async_ok = torch.equal(res[0], res[1]) and not torch.equal(res[0], ParamArena(clip.CLIP(MODELS["test-tiny"]).initialize_parameters(1), torch.device("cpu")).flat)
-    torch.save(dict(loss=loss.detach(), stats=stats, dfi=fi.grad, dft=ft.grad, dls=lsp.grad, gsum_ok=gsum_ok, async_ok=async_ok),
+    # overlapped schedule: buckets reduced from INSIDE backward (GradReducer) as the gradient slots are reported block by
+    # block, logit_scale's gradient arriving through plain autograd (outside the arena) - must equal the synchronous form
+    torch.manual_seed(5)
+    mm = clip.CLIP(MODELS["test-tiny"]).initialize_parameters(1)
+    a3 = ParamArena(mm, torch.device("cpu"))
+    opt = coptim.AdamW(_M(a3), lr=1e-3)
+    red = par.GradReducer(a3, max_bucket_elems=300_000)
+    assert red.active and len(red.buckets) > 2
+    early = []
+    a3.gflat.copy_(torch.sin(torch.arange(a3.total, dtype=torch.float32) * 0.37 + rank))
+    for _ in range(2):                         # (as above, the second step reduces the first step's sums again)
+        for p_ in a3.params.values():
+            p_.grad = None
+        red.begin()
+        # "backward": towers report block groups from the last block to the first, then the leftovers; slots are written first
+        off_ls = a3.offsets["logit_scale"]
+        fill = a3.gflat.clone()
+        a3.gflat[off_ls] = 0.0
+        for prefix in ("visual.transformer.resblocks.", "transformer.resblocks."):
+            layers = sorted({int(n[len(prefix):].split(".")[0]) for n in a3.names if n.startswith(prefix)}, reverse=True)
+            for l in layers:
+                a3.publish_grads([n for n in a3.names if n.startswith(f"{prefix}{l}.")])   # .grad -> slot, listener told
+        rest = [n for n in a3.names if ".resblocks." not in n and n != "logit_scale"]
+        a3.publish_grads(rest)
+        a3.params["logit_scale"].grad = fill[off_ls].clone()          # what autograd would hand over
+        pend = red.finish()
+        early.append(red.fired_early)
+        assert a3.params["logit_scale"].grad.data_ptr() == a3.g["logit_scale"].data_ptr()
+        opt.step(grad_scale=0.5, pending=pend)
+    overlap_ok = torch.equal(a3.flat, res[0]) and min(early) >= 1
+    torch.save(dict(loss=loss.detach(), stats=stats, dfi=fi.grad, dft=ft.grad, dls=lsp.grad, gsum_ok=gsum_ok, async_ok=async_ok, overlap_ok=overlap_ok, early=early),
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -100,6 +130,7 @@ def test_dp_contrastive_matches_single_process(tmp_path):
         assert torch.allclose(o["dft"], ft.grad[r * nloc:(r + 1) * nloc], atol=1e-6)
         assert o["gsum_ok"]
         assert o["async_ok"]                                         # bucket-wise AdamW under async all-reduce == one pass
+        assert o["overlap_ok"], o["early"]                           # buckets reduced from inside backward == the same
     assert abs(dls.item() - ls.grad.item()) < 1e-6
 
 

@@ -162,3 +162,28 @@ def test_caption_checkpoint_with_hf_attention_buffers_loads_strict():
         for k in sd:
             assert torch.equal(got[k].cpu(), sd[k]), k
     assert len(old) == len(sd) + 2 * geo.n_layer            # the caller's dict is left untouched
+
+
+def test_gemm_tune_table_roundtrip_and_source_hash(tmp_path, monkeypatch):
+    """The persisted autotune table: JSON round trip, ignored when made for other kernel sources, env file wins."""
+    import json
+    from cclip_hip import ops
+    saved = dict(ops._TUNED)
+    try:
+        ops._TUNED.clear()
+        k = ops._key_str(("bfloat16", 51200, 2304, 768, True, True, 0, False, True, False, False, True, 1, False, False))
+        assert k == "bfloat16|51200|2304|768|1|1|0|0|1|0|0|1|1|0|0"
+        ops._TUNED[k] = (3, 1)
+        path = str(tmp_path / "tune.json")
+        assert ops.save_tuned_table(path) == path
+        blob = json.load(open(path))
+        assert blob["kernel_source_hash"] == ops.kernel_source_hash() and blob["table"][k] == [3, 1]
+        ops._TUNED.clear()
+        assert ops.load_tuned_table(path) == 1 and ops._TUNED[k] == (3, 1)
+        blob["kernel_source_hash"] = "0" * 16                       # a table for other kernels is not used
+        json.dump(blob, open(path, "w"))
+        ops._TUNED.clear()
+        assert ops.load_tuned_table(path) == 0 and not ops._TUNED
+    finally:
+        ops._TUNED.clear()
+        ops._TUNED.update(saved)
