@@ -103,6 +103,33 @@ class ParamArena:
                 n_adopted += 1
         return n_adopted
 
+    # ---- static loss scale of the fp16 operand mode ----
+    # The hand-written backward is linear in the upstream gradient.  With fp16 operands its 16-bit dY / dX stream carries
+    # the 1/N of a mean loss unscaled, and at realistic N (1024 pairs; 256 x 40 caption tokens) most of it would be fp16
+    # subnormals.  The backward therefore runs on S x the upstream gradient (S = LOSS_SCALE_FP16, a power of two: exact) and
+    # the slots it wrote are multiplied by 1/S afterwards; slots that are being accumulated into are pre-multiplied by S.
+    LOSS_SCALE_FP16 = 4096.0
+
+    def loss_scale(self) -> float:
+        return self.LOSS_SCALE_FP16 if self.shadow_dtype == torch.float16 else 1.0
+
+    def slot_ranges(self, names):
+        """maximal contiguous [start, end) element ranges of the flat buffers covering the named parameters' slots"""
+        spans = sorted((self.offsets[n], self.offsets[n] + (self.params[n].numel() + _ALIGN - 1) // _ALIGN * _ALIGN) for n in names)
+        out = []
+        for s, e in spans:
+            if out and s <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], e)
+            else:
+                out.append([s, e])
+        return [(s, e) for s, e in out]
+
+    def scale_grads(self, names, alpha: float) -> None:
+        if alpha == 1.0:
+            return
+        for s, e in self.slot_ranges(names):
+            ops.scale_f32(self.gflat[s:e], alpha)
+
     def notify_grads(self, grad_views, streams=()) -> None:
         if self.grad_listener is not None:
             self.grad_listener(grad_views, streams)

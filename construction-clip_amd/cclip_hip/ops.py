@@ -654,5 +654,12 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr: float, beta1=0.9, beta2=
                                c_float(grad_scale), c_int(mode), _p(bf16_shadow), _stream()), "cclip_adamw_step")
 
 
+def scale_f32(x: torch.Tensor, alpha: float) -> None:
+    """x *= alpha in place (flat fp32, numel % 4 == 0, 16-byte aligned)"""
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    check(lib.cclip_scale_f32(_p(x), c_long(x.numel()), c_float(alpha), _stream()), "cclip_scale_f32")
+
+
 def cast_f32_to_bf16(src, dst) -> None:
     check(_fn("cclip_cast_f32_to_bf16", dst)(_p(src), _p(dst), c_long(src.numel()), _stream()), "cclip_cast_f32_to_bf16")

@@ -351,7 +351,7 @@ class BlockStack:
                               dgamma=gr["ln1_w"] if gr is not None else None, dbeta=gr["ln1_b"] if gr is not None else None,
                               accumulate=A("ln1_w") if gr is not None else False, ws=ws)
             dxb = dxb_in
-            hook = getattr(self, "grad_hook", None)
+            hook = getattr(self, "grad_hook", None) if getattr(self, "grad_hook_enabled", True) else None
             if hook is not None and gr is not None:
                 # this layer's last gradient kernels are enqueued (weights on the side stream, LayerNorm affines on the main
                 # one): a data-parallel reducer may start this layer's all-reduce now, under the remaining layers' backward

@@ -277,6 +277,10 @@ class CLIP(nn.Module):
         M = B * T
         dev = dfeat.device
         dfeat = dfeat.contiguous().float()
+        S = ar.loss_scale()                       # fp16 operands: backward on S x dfeat, slots unscaled at the end
+        if S != 1.0:
+            dfeat = dfeat * S
+            ar.scale_grads([n for n in self._rt["vis_names"] if acc[id(g[n])]], S)
 
         def A(name):
             return acc[id(g[name])]
@@ -291,6 +295,7 @@ class CLIP(nn.Module):
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["visual.ln_post.weight"],
                           dbeta=g["visual.ln_post.bias"], accumulate=A("visual.ln_post.weight"),
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
+        st.grad_hook_enabled = S == 1.0         # (under a loss scale the slots are final only after the unscale below)
         dxb = st.backward(dx, dxb, c["saved"], acc)
         ops.layernorm_bwd(dx, c["x0"], p["visual.ln_pre.weight"].data, c["st0"][0], c["st0"][1], rows=M, dx_out=dx,
                           dx_out_bf16=dxb, dgamma=g["visual.ln_pre.weight"], dbeta=g["visual.ln_pre.bias"],
@@ -310,6 +315,7 @@ class CLIP(nn.Module):
                 gw.add_(gpad[:, :gw.shape[1]])
             else:
                 gw.copy_(gpad[:, :gw.shape[1]])
+        ar.scale_grads(self._rt["vis_names"], 1.0 / S)
         ar.publish_grads(self._rt["vis_names"])
 
     # -- text tower -----------------------------------------------------------------------------
@@ -358,6 +364,10 @@ class CLIP(nn.Module):
         M = B * L
         dev = dfeat.device
         dfeat = dfeat.contiguous().float()
+        S = ar.loss_scale()
+        if S != 1.0:
+            dfeat = dfeat * S
+            ar.scale_grads([n for n in self._rt["txt_names"] if acc[id(g[n])]], S)
 
         def A(name):
             return acc[id(g[name])]
@@ -372,6 +382,7 @@ class CLIP(nn.Module):
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["ln_final.weight"],
                           dbeta=g["ln_final.bias"], accumulate=A("ln_final.weight"),
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
+        st.grad_hook_enabled = S == 1.0
         dxb = st.backward(dx, dxb, c["saved"], acc)
         gpos = g["positional_embedding"]
         if L < geo.context_length and not A("positional_embedding"):
@@ -381,6 +392,7 @@ class CLIP(nn.Module):
         if not A("token_embedding.weight"):
             g["token_embedding.weight"].zero_()
         ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M)
+        ar.scale_grads(self._rt["txt_names"], 1.0 / S)
         ar.publish_grads(self._rt["txt_names"])
 
     # -- public API (same names / argument meaning as openai/CLIP) --------------------------------

@@ -509,14 +509,19 @@ class ClipCaptionModel(nn.Module):
             return acc[id(g[name])]
 
         B, P, D = dout.shape[0], self.prefix_length, self.model_embedding_size
-        d32 = dout.detach().float().contiguous().view(B, P * D)
+        LS = ar.loss_scale()
+        names = [n for n in ar.names if n.startswith("clip_project.") and ar.params[n].requires_grad]
+        d32 = (dout.detach().float() * LS).contiguous().view(B, P * D)
+        if LS != 1.0:
+            ar.scale_grads([n for n in names if A(n)], LS)
         d16 = torch.empty(B, P * D, device=dout.device, dtype=self.compute_dtype)
         ops.cast_f32_to_bf16(d32, d16)
         if self._mstack is not None:
             self._tmapper_backward(msave, d32.view(B * P, D), d16.view(B * P, D), B, P, acc, A)
         else:
             self._mlp_mapper_backward(msave, d16, P * D, A)
-        ar.publish_grads([n for n in ar.names if n.startswith("clip_project.") and ar.params[n].requires_grad])
+        ar.scale_grads(names, 1.0 / LS)
+        ar.publish_grads(names)
 
     def _mapper_only(self, prefix: torch.Tensor) -> torch.Tensor:
         """`model.clip_project(prefix)` as the inference scripts call it (test.py:540, application.py:104); differentiable
@@ -673,6 +678,10 @@ class ClipCaptionModel(nn.Module):
         def A(name):
             return acc[id(g[name])]
 
+        LS = ar.loss_scale()         # fp16 operands: dlog_b arrives LS x too large (callers), and so is every slot written here
+        trainable_names = [n for n in ar.names if ar.params[n].requires_grad]
+        if LS != 1.0:
+            ar.scale_grads([n for n in trainable_names if A(n)], LS)
         wte_name = "model.transformer.wte.weight"
         wrote_wte = False
         if not frozen:
@@ -705,7 +714,8 @@ class ClipCaptionModel(nn.Module):
                 self._tmapper_backward(c["msave"], dx, dxb, B, S, acc, A)
         elif p["clip_project.model.2.weight"].requires_grad:
             self._mlp_mapper_backward(c["msave"], dxb.view(B, S * D)[:, :P * D], S * D, A)
-        ar.publish_grads([n for n in ar.names if ar.params[n].requires_grad])
+        ar.scale_grads(trainable_names, 1.0 / LS)
+        ar.publish_grads(trainable_names)
 
 
 class ClipCaptionPrefix(ClipCaptionModel):
@@ -753,6 +763,9 @@ class _CaptionLogits(torch.autograd.Function):
         Vp = (V + 7) // 8 * 8
         d = torch.zeros(R, Vp, device=dlogits.device, dtype=torch.float32)
         d[:, :V].copy_(dlogits)                                             # re-stride onto the 8-padded layout (plumbing)
+        LS = ctx.model._arena.loss_scale()
+        if LS != 1.0:
+            ops.scale_f32(d.view(-1), LS)                                   # before the 16-bit cast (fp16 loss scale)
         db = torch.empty(R, Vp, device=d.device, dtype=ctx.model.compute_dtype)
         ops.cast_f32_to_bf16(d, db)
         ctx.model._backward_from_dlogits(ctx.c, db[:, :V], ctx.rows, ctx.lm)
@@ -776,7 +789,8 @@ class _CaptionLoss(torch.autograd.Function):
         loss_rows = torch.empty(R, device=dev, dtype=torch.float32)
         V = logits.shape[1]
         dlog = torch.zeros(R, (V + 7) // 8 * 8, device=dev, dtype=model.compute_dtype)[:, :V] if need_grad else None   # finite pads
-        ops.xent_rows(logits, labels, loss_row=loss_rows, dlogits=dlog, grad_scale=1.0 / max(kept, 1), ignore_index=0)
+        ops.xent_rows(logits, labels, loss_row=loss_rows, dlogits=dlog, grad_scale=model._arena.loss_scale() / max(kept, 1),
+                      ignore_index=0)                                        # (fp16 operands: 16-bit dlogits under the loss scale)
         out = torch.empty(1, device=dev, dtype=torch.float32)
         ops.reduce_dot(loss_rows, None, out, alpha=1.0 / max(kept, 1))
         if need_grad:

@@ -223,6 +223,10 @@ int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      int32_t correct_bias, float grad_scale, int32_t mode, void* bf16_shadow,
                      hipStream_t stream);
 int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+/* x[i] *= alpha over n fp32 elements (n % 4 == 0, 16-byte aligned).  The fp16 operand mode runs its backward under a static
+ * power-of-two loss scale (the 16-bit gradient stream of a mean loss over thousands of rows would otherwise sink into
+ * fp16 subnormals); this undoes it on the flat gradient arena. */
+int cclip_scale_f32(float* x, int64_t n, float alpha, hipStream_t stream);
 
 /* ---- device-side preprocess --------------------------------------------------------------------
  * openai/CLIP's _transform(n) = Resize(n, BICUBIC) -> CenterCrop(n) -> ToTensor -> Normalize on a decoded 8-bit RGB image
