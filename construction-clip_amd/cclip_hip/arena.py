@@ -9,7 +9,7 @@ ViT-B/32) irrelevant.  nn.Parameter objects stay ordinary parameters (state_dict
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -47,6 +47,11 @@ class ParamArena:
                 self.g[n] = self.gflat[off:off + k].view(p.shape)
                 self.b[n] = self.bflat[off:off + k].view(p.shape)
         self._stamp = None
+        self.shadow_gen = 0                      # bumped whenever the 16-bit shadows are rewritten (cast or fused optimiser)
+        self.tflat: Optional[torch.Tensor] = None  # transposed 16-bit shadows of the registered matrices (same offsets)
+        self.t: Dict[str, torch.Tensor] = {}
+        self._t_table = None
+        self._t_gen = -1
         self.accumulating: Dict[int, bool] = {}
         # set by clip.parallel.GradReducer: called as listener(grad_views, producer_streams) from inside the hand-written
         # backward whenever a group of gradient slots has had its last kernel ENQUEUED (not finished: the streams say where)
@@ -63,9 +68,41 @@ class ParamArena:
         if force or stamp != self._stamp:
             ops.cast_f32_to_bf16(self.flat, self.bflat)
             self._stamp = stamp
+            self.shadow_gen += 1
 
     def mark_shadows_fresh(self) -> None:
         self._stamp = self._current_stamp()
+        self.shadow_gen += 1
+
+    # ---- transposed shadows (dgrad operands) ----
+    def register_transposed(self, names) -> None:
+        """Keep a transposed 16-bit copy of these 2-D parameters ([out, in] -> [in, out]) in `self.t[name]`, rebuilt by ONE
+        batched launch whenever the shadows changed (refresh_transposed).  The backward of an nn.Linear layer then reads its
+        weight K-contiguously, like the forward (csrc/transpose16.hip)."""
+        names = [n for n in names if self.params[n].dim() == 2]
+        if not names:
+            return
+        if self.tflat is None:
+            self.tflat = torch.zeros(self.total, device=self.device, dtype=self.shadow_dtype)
+        rows, tiles = [], 0
+        for n in names:
+            r, c = self.params[n].shape
+            off = self.offsets[n]
+            self.t[n] = self.tflat[off:off + r * c].view(c, r)
+            rows.append([off, off, r, c])
+            tiles = max(tiles, ((r + 63) // 64) * ((c + 63) // 64))
+        old = [] if self._t_table is None else self._t_table[0].tolist()
+        table = torch.tensor(old + rows, dtype=torch.int64, device=self.device)
+        self._t_table = (table, max(tiles, 0 if self._t_table is None else self._t_table[1]))
+        self._t_gen = -1
+
+    def refresh_transposed(self) -> None:
+        if self._t_table is None:
+            return
+        self.refresh_shadows()
+        if self._t_gen != self.shadow_gen:
+            ops.transpose16_batched(self.bflat, self.tflat, self._t_table[0], self._t_table[1])
+            self._t_gen = self.shadow_gen
 
     def intact(self) -> bool:
         """False if someone re-pointed a parameter away from the arena (module.to(), .half(), ...)."""

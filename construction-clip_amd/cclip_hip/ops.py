@@ -654,6 +654,13 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr: float, beta1=0.9, beta2=
                                c_float(grad_scale), c_int(mode), _p(bf16_shadow), _stream()), "cclip_adamw_step")
 
 
+def transpose16_batched(src_base: torch.Tensor, dst_base: torch.Tensor, table_dev: torch.Tensor, max_tiles: int) -> None:
+    """table_dev: int64 [n, 4] on the device = (src element offset, dst element offset, rows, cols) per matrix"""
+    assert src_base.dtype in HALF_TYPES and dst_base.dtype == src_base.dtype and table_dev.dtype == torch.int64 and table_dev.is_cuda
+    check(lib.cclip_transpose16_batched(_p(src_base), _p(dst_base), _p(table_dev), c_int(table_dev.shape[0]), c_int(max_tiles),
+                                        _stream()), "cclip_transpose16_batched")
+
+
 def scale_f32(x: torch.Tensor, alpha: float) -> None:
     """x *= alpha in place (flat fp32, numel % 4 == 0, 16-byte aligned)"""
     _req(x, torch.float32, "x")

@@ -36,6 +36,8 @@ class BlockWeights:
     w_fc: torch.Tensor; b_fc: torch.Tensor
     w_proj: torch.Tensor; b_proj: torch.Tensor
     grads: Optional[Dict[str, torch.Tensor]] = None    # same field names -> fp32 grad views (None = frozen)
+    wt: Optional[Dict[str, torch.Tensor]] = None       # nn.Linear layout: transposed ([in, out]) 16-bit copies of the four
+                                                       # matrices for the dgrad GEMMs (ParamArena.register_transposed)
 
 
 @dataclass
@@ -265,6 +267,8 @@ class BlockStack:
         dact = _DACT[geo.act]
         bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
         trainable = any(b.grads is not None for b in self.blocks)
+        if getattr(self, "refresh_transposed", None) is not None:
+            self.refresh_transposed()            # rebuilt once per optimiser step (no-op while the shadows are unchanged)
         side = None
         if trainable and os.environ.get("CCLIP_WGRAD_STREAM", "1") == "1" and dev.type == "cuda":
             if getattr(self, "_side", None) is None:
@@ -311,17 +315,24 @@ class BlockStack:
             def A(name, gr=gr):
                 return acc.get(id(gr[name]), False)
 
+            def wd(name, w=w):
+                """B operand of a dgrad GEMM dX = dY . W: the transposed shadow (K-contiguous, forward layout) when the arena
+                keeps one, else the weight itself read K-strided ([out, in]) / K-contiguously (Conv1D [in, out])"""
+                if w.wt is not None:
+                    return w.wt[name], True
+                return getattr(w, name), not kc
+
             # ---- MLP branch ----
             if gr is not None:
                 def f1(sc, dxb=dxb, g=g, gr=gr):
                     self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
                 leaf(f1)
-            ops.gemm_bf16(dxb, w.w_proj, b_kcontig=not kc, act=dact, aux=h, out_bf16=dh, M=M)
+            ops.gemm_bf16(dxb, *wd("w_proj"), act=dact, aux=h, out_bf16=dh, M=M)
             if gr is not None:
                 def f2(sc, dh=dh, xn2=xn2, gr=gr):
                     self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
                 leaf(f2)
-            ops.gemm_bf16(dh, w.w_fc, b_kcontig=not kc, out_bf16=dsm, M=M)
+            ops.gemm_bf16(dh, *wd("w_fc"), out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
             ops.layernorm_bwd(dsm, x_mid, w.ln2_w, m2, r2, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_mid,
                               dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
@@ -332,7 +343,7 @@ class BlockStack:
                 def f3(sc, dxb=dxb, a=a, gr=gr):
                     self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
                 leaf(f3)
-            ops.gemm_bf16(dxb, w.w_o, b_kcontig=not kc, out_bf16=dsm, M=M)
+            ops.gemm_bf16(dxb, *wd("w_o"), out_bf16=dsm, M=M)
             if geo.head_dim == 64:
                 ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
                                   dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
@@ -345,7 +356,7 @@ class BlockStack:
                     gbq = gr.get("b_qkv")                    # TransformerMapper's q / kv projections have no bias
                     self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc, gbq, A("b_qkv", gr) if gbq is not None else False)
                 leaf(f4)
-            ops.gemm_bf16(dqkv, w.w_qkv, b_kcontig=not kc, out_bf16=dsm, M=M)
+            ops.gemm_bf16(dqkv, *wd("w_qkv"), out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
             ops.layernorm_bwd(dsm, x_in, w.ln1_w, m1, r1, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_in,
                               dgamma=gr["ln1_w"] if gr is not None else None, dbeta=gr["ln1_b"] if gr is not None else None,

@@ -182,6 +182,11 @@ class CLIP(nn.Module):
         ar = ParamArena(self, dev, self.compute_dtype)
         geo = self.geo
 
+        import os
+        # transposed weight shadows: every dgrad GEMM then reads its weight K-contiguously (CCLIP_TRANSPOSED_SHADOWS=0: the
+        # K-strided reads of the [out, in] weights, as in round 1)
+        use_wt = os.environ.get("CCLIP_TRANSPOSED_SHADOWS", "1") == "1"
+
         def stack(prefix: str, width: int, heads: int, layers: int, tokens: int, causal: bool) -> BlockStack:
             blocks: List[BlockWeights] = []
             for i in range(layers):
@@ -190,7 +195,11 @@ class CLIP(nn.Module):
                     name = f"{prefix}.resblocks.{i}.{key}"
                     kw[f] = ar.b[name] if f in _MATS else ar.params[name].data
                     grads[f] = ar.g[name]
-                blocks.append(BlockWeights(grads=grads, **kw))
+                wt = None
+                if use_wt:
+                    ar.register_transposed([f"{prefix}.resblocks.{i}.{_BLOCK_KEYS[f]}" for f in _MATS])
+                    wt = {f: ar.t[f"{prefix}.resblocks.{i}.{_BLOCK_KEYS[f]}"] for f in _MATS}
+                blocks.append(BlockWeights(grads=grads, wt=wt, **kw))
             return BlockStack(StackGeometry(width, heads, tokens, True, ops.ACT_QUICKGELU, causal), blocks, Scratch(dev),
                               self.compute_dtype)
 
@@ -204,6 +213,8 @@ class CLIP(nn.Module):
         )
         self._rt["vis"].fp8, self._rt["txt"].fp8 = getattr(self, "_fp8_projections", (False, False))
         self._rt["vis"].grad_hook = self._rt["txt"].grad_hook = ar.notify_grads
+        if use_wt:
+            self._rt["vis"].refresh_transposed = self._rt["txt"].refresh_transposed = ar.refresh_transposed
 
     def fp8_projections(self, enabled: bool = True, text: bool = False):
         """INFERENCE ONLY: run the LayerNorm-fed projections (qkv, fc) of the image tower - and, with text=True, of the text
@@ -514,6 +525,7 @@ class _BothTowers(torch.autograd.Function):
         dev = (dfi if dfi is not None else dft).device
         s0, s1 = model._tower_streams(dev)
         cur = torch.cuda.current_stream()
+        model._arena.refresh_transposed()          # before the fork: both towers' dgrad GEMMs read the transposed shadows
         s0.wait_stream(cur); s1.wait_stream(cur)
         if dfi is not None:
             with torch.cuda.stream(s0):

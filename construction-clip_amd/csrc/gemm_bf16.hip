@@ -103,6 +103,7 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   if (!d || !d->A || !d->B || d->M <= 0 || d->N <= 0 || d->K <= 0) return CCLIP_ERR_ARG;
   if ((d->lda & 7) || (d->ldb & 7) || (d->ldc & 7)) return CCLIP_ERR_ARG;
   if (!d->a_kcontig && d->b_kcontig) return CCLIP_ERR_ARG;   // (0,1) is not a layout this path uses
+  if (!d->a_kcontig && !d->b_kcontig && (d->out_pre_bf16 || d->act != CCLIP_ACT_NONE || d->aux)) return CCLIP_ERR_ARG;   // wgrad epilogue forms
   if ((uintptr_t)d->A & 15 || (uintptr_t)d->B & 15) return CCLIP_ERR_ARG;
   if (d->residual && (d->ldr & 3)) return CCLIP_ERR_ARG;
   if (d->aux && (d->ldaux & 7)) return CCLIP_ERR_ARG;

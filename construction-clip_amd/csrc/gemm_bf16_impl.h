@@ -245,6 +245,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   }
   int cur = 0;                                                   // stage holding tile kt
   constexpr bool WG_LAYOUT = !A_KC && !B_KC && MT <= 4;     // (the 128x64-per-wave kernels have no registers left for it)
+  // Column order of the B fragments.  The n-permutation (nperm above) exists for the epilogue: a lane then owns runs of 8
+  // consecutive output columns.  Read from a K-STRIDED tile it costs LDS bandwidth: the four 4-column pieces a
+  // ds_read_b64_tr_b16 gathers all sit in the SAME half of their 16-byte chunks, so the 32 lanes of a bank group can only
+  // reach half of the 64 banks - a 2-way conflict on every B read (the DMA image is 16-byte granular: no swizzle fixes it).
+  // The weight-gradient layout (both operands K-strided, contraction over tokens: thousands of K iterations, a negligible
+  // epilogue) therefore reads B in NATURAL column order - conflict-free like A - and has its own 4-column epilogue.
+  constexpr int BPERM = (A_KC || B_KC) ? 1 : 0;
   f32x4 accb[WG_LAYOUT ? MT : 1];
   bf16x8 ones8;
 #pragma unroll
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       xf[0][mt] = A_KC ? frag_rows(At, a_row + 16 * mt, 0, lane) : frag_cols<0>(At, a_row, mt, 0, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      wf[0][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 0, lane) : frag_cols<1>(Bt, b_row, nt, 0, lane);
+      wf[0][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 0, lane) : frag_cols<BPERM>(Bt, b_row, nt, 0, lane);
     if (DMA && ILV_EARLY) {   // program order: k-step 0 reads, DMA, k-step 1 reads
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       xf[1][mt] = A_KC ? frag_rows(At, a_row + 16 * mt, 1, lane) : frag_cols<0>(At, a_row, mt, 1, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      wf[1][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 1, lane) : frag_cols<1>(Bt, b_row, nt, 1, lane);
+      wf[1][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 1, lane) : frag_cols<BPERM>(Bt, b_row, nt, 1, lane);
     if (DMA && ILV) {     // after the fragment reads in program order (the DMA writes LDS: the reads may not sink below it)
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
@@ -388,13 +395,64 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = bn0 + wn0 + 32 * (nt >> 1) + 8 * (lane >> 4) + 4 * (nt & 1) + r;
+          const int n = BPERM ? bn0 + wn0 + 32 * (nt >> 1) + 8 * (lane >> 4) + 4 * (nt & 1) + r
+                              : bn0 + wn0 + 16 * nt + 4 * (lane >> 4) + r;
           if (n < p.N) {
             if (p.split_ws) p.colsum_ws[(long)blockIdx.y * p.N + n] = accb[nt][r];
             else p.colsum_dst[n] = (p.colsum_acc ? p.colsum_dst[n] : 0.f) + accb[nt][r];
           }
         }
     }
+  }
+  if constexpr (!BPERM) {
+    // ---- weight-gradient epilogue (natural B columns): lane holds, per (mt, nt), columns n0..n0+3 of row m ----
+    // forms the dispatcher admits for this layout: raw split-K slabs, or alpha*acc (+ bias) (+ fp32 residual) -> fp32 / 16-bit
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = bm0 + wm0 + 16 * mt + li;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n0 = bn0 + wn0 + 16 * nt + 4 * g;
+        if (n0 >= p.N) continue;
+        float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+        const bool full = n0 + 4 <= p.N;
+        if (p.split_ws) {                                    // (split-K requires N % 4 == 0: always a full run)
+          *(float4*)(p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
+          continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= p.alpha;
+          if (p.bias && n0 + r < p.N) v[r] += p.bias[n0 + r];
+        }
+        if (p.residual) {
+          const float* rp = p.residual + (long)m * p.ldr + n0;
+          if (full) { const float4 t = *(const float4*)rp; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] += rp[r];
+          }
+        }
+        if (p.out_f32) {
+          float* o = p.out_f32 + (long)m * p.ldc + n0;
+          if (full) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n0 + r < p.N) o[r] = v[r];
+          }
+        }
+        if (p.out_bf16) {
+          bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
+          if (full) { bf16x4 t = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *(bf16x4*)o = t; }
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+          }
+        }
+      }
+    }
+    return;
   }
   // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
   // Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then the

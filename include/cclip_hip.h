@@ -223,6 +223,13 @@ int cclip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      int32_t correct_bias, float grad_scale, int32_t mode, void* bf16_shadow,
                      hipStream_t stream);
 int cclip_cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+/* Batched out-of-place transpose of 16-bit matrices (bf16 or fp16: elements are moved, not interpreted): for i < n_matrices,
+ * dst_base[table[i].dst_off ...] as [cols, rows] = transpose of src_base[table[i].src_off ...] as [rows, cols];
+ * table_dev = n_matrices x {src_off, dst_off, rows, cols} int64 in DEVICE memory (element offsets), max_tiles = the largest
+ * ceil(rows/64) * ceil(cols/64) of the batch.  Rebuilds the transposed weight shadows the dgrad GEMMs read (one launch per
+ * optimiser step), so that dX = dY . W runs in the forward operand layout. */
+int cclip_transpose16_batched(const void* src_base, void* dst_base, const int64_t* table_dev, int32_t n_matrices,
+                              int32_t max_tiles, hipStream_t stream);
 /* x[i] *= alpha over n fp32 elements (n % 4 == 0, 16-byte aligned).  The fp16 operand mode runs its backward under a static
  * power-of-two loss scale (the 16-bit gradient stream of a mean loss over thousands of rows would otherwise sink into
  * fp16 subnormals); this undoes it on the flat gradient arena. */

@@ -280,8 +280,11 @@ def test_two_tower_streams_equal_one_stream_at_bs256(monkeypatch):
         # no synchronize: the clones below are ordered behind backward() on the caller's stream only
         grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
     torch.cuda.synchronize()
-    bad = [k for k in grads["1"] if not torch.equal(grads["1"][k], grads["2"][k])]
+    # token_embedding.weight is accumulated with fp32 atomics (csrc/embed.hip: embed_scatter_add): rows that share a token
+    # id add in hardware order, so it is compared to rounding, everything else bit for bit
+    bad = [k for k in grads["1"] if k != "token_embedding.weight" and not torch.equal(grads["1"][k], grads["2"][k])]
     assert not bad, bad[:5]
+    assert rel(grads["2"]["token_embedding.weight"], grads["1"]["token_embedding.weight"]) < 1e-6
     assert len(ops._TUNED) > 0          # (the comparison is bitwise only because both schedules share the tuned table)
 
 

@@ -322,3 +322,42 @@ def test_adamw_matches_hf_form():
     src = torch.randn(1024, device="cuda", generator=g); dst = torch.empty(1024, device="cuda", dtype=torch.bfloat16)
     o.cast_f32_to_bf16(src, dst)
     assert torch.equal(dst, src.bfloat16())
+
+
+def test_transpose16_batched_and_arena_transposed_shadows():
+    """csrc/transpose16.hip: batched 16-bit transposes (full 64x64 tiles and ragged edges), and the arena's transposed
+    weight shadows following the masters through an optimiser step."""
+    from cclip_hip import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(768, 2304), (64, 64), (200, 72), (1, 9), (3072, 768)]
+    mats = [torch.randn(r, c, device="cuda", generator=g).bfloat16() for r, c in shapes]
+    src = torch.cat([m.flatten() for m in mats] + [torch.zeros(8, device="cuda", dtype=torch.bfloat16)])
+    dst = torch.full_like(src, float("nan"))
+    offs, table, tiles = 0, [], 0
+    for r, c in shapes:
+        table.append([offs, offs, r, c]); offs += r * c
+        tiles = max(tiles, ((r + 63) // 64) * ((c + 63) // 64))
+    ops.transpose16_batched(src, dst, torch.tensor(table, dtype=torch.int64, device="cuda"), tiles)
+    for (off, _, r, c), m in zip(table, mats):
+        assert torch.equal(dst[off:off + r * c].view(c, r), m.t().contiguous()), (r, c)
+    # arena: transposed shadows == shadows^T, before and after a fused AdamW step
+    import clip
+    from clip import optim as coptim
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    geo = MODELS["test-small"]
+    model = clip.build_model(init_state_dict(geo, 3)).cuda().train()
+    img, txt = synthetic_images(6, geo, 4).cuda(), synthetic_text(6, geo, 5).cuda()
+    opt = coptim.AdamW(model, lr=1e-2)
+    for _ in range(2):
+        opt.zero_grad()
+        li, lt = model(img, txt)
+        lab = torch.arange(6, device="cuda")
+        ((torch.nn.functional.cross_entropy(li, lab) + torch.nn.functional.cross_entropy(lt, lab)) / 2).backward()
+        ar = model.arena
+        assert ar.t, "transposed shadows are on by default"
+        for n, tv in ar.t.items():
+            assert torch.equal(tv, ar.b[n].t()), n                       # what backward just used
+        opt.step()
+    ar.refresh_transposed()
+    for n, tv in ar.t.items():
+        assert torch.equal(tv, ar.b[n].t()) and torch.equal(ar.b[n].float(), ar.params[n].data.to(ar.b[n].dtype).float()), n
