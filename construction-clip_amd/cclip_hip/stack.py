@@ -65,10 +65,10 @@ def wgrad_splits(n_out: int, k_in: int, tokens: int) -> int:
 
 def wgrad_candidates(n_out: int, k_in: int, tokens: int):
     """(tile_config, split_k) candidates for the wgrad autotuner: aim the grid at 1x / 2x / 3x the machine's
-    concurrent workgroups (512 for the 128x128 tile, 256 for the 256x128 and 256x256 tiles), >= 4 K-tiles per split."""
+    concurrent workgroups (512 for the 128x128 tile, 256 for the 256x128, 256x256 and 192x256 tiles), >= 4 K-tiles per split."""
     nkt = (tokens + 63) // 64
     cands = []
-    for cfg, em, en, slots in ((1, 128, 128, 512), (2, 256, 128, 256), (3, 256, 256, 256)):
+    for cfg, em, en, slots in ((1, 128, 128, 512), (2, 256, 128, 256), (3, 256, 256, 256), (5, 192, 256, 256)):
         tiles = ((n_out + em - 1) // em) * ((k_in + en - 1) // en)
         for mult in (1, 2, 3):
             s = max(1, min(64, (slots * mult) // max(tiles, 1)))
@@ -327,12 +327,12 @@ class BlockStack:
                 def f1(sc, dxb=dxb, g=g, gr=gr):
                     self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
                 leaf(f1)
-            ops.gemm_bf16(dxb, *wd("w_proj"), act=dact, aux=h, out_bf16=dh, M=M)
+            ops.gemm_bf16(dxb, wd("w_proj")[0], b_kcontig=wd("w_proj")[1], act=dact, aux=h, out_bf16=dh, M=M)
             if gr is not None:
                 def f2(sc, dh=dh, xn2=xn2, gr=gr):
                     self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
                 leaf(f2)
-            ops.gemm_bf16(dh, *wd("w_fc"), out_bf16=dsm, M=M)
+            ops.gemm_bf16(dh, wd("w_fc")[0], b_kcontig=wd("w_fc")[1], out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
             ops.layernorm_bwd(dsm, x_mid, w.ln2_w, m2, r2, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_mid,
                               dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
@@ -343,7 +343,7 @@ class BlockStack:
                 def f3(sc, dxb=dxb, a=a, gr=gr):
                     self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
                 leaf(f3)
-            ops.gemm_bf16(dxb, *wd("w_o"), out_bf16=dsm, M=M)
+            ops.gemm_bf16(dxb, wd("w_o")[0], b_kcontig=wd("w_o")[1], out_bf16=dsm, M=M)
             if geo.head_dim == 64:
                 ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
                                   dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
@@ -356,7 +356,7 @@ class BlockStack:
                     gbq = gr.get("b_qkv")                    # TransformerMapper's q / kv projections have no bias
                     self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc, gbq, A("b_qkv", gr) if gbq is not None else False)
                 leaf(f4)
-            ops.gemm_bf16(dqkv, *wd("w_qkv"), out_bf16=dsm, M=M)
+            ops.gemm_bf16(dqkv, wd("w_qkv")[0], b_kcontig=wd("w_qkv")[1], out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
             ops.layernorm_bwd(dsm, x_in, w.ln1_w, m1, r1, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_in,
                               dgamma=gr["ln1_w"] if gr is not None else None, dbeta=gr["ln1_b"] if gr is not None else None,

@@ -48,11 +48,13 @@ __device__ __forceinline__ int fswz(int kr) { return ((kr & 3) << 2) | ((kr >> 2
 // wave-instructions of 1 KiB; the NSUB*16 instructions are dealt round-robin to the NW waves ----
 // PERM: LDS row position rp of a K-contiguous sub-tile holds tile row 64*(rp>>6) + nperm((rp>>4)&3, rp&15)
 // (free at staging time because the DMA source address is per lane), so fragment reads stay natural.
-template <int KC, int PERM, int NSUB, int NW>
+// NINSTR: wave-instructions actually issued (default: whole sub-tiles); a 192-row A tile needs 24 of its 32
+template <int KC, int PERM, int NSUB, int NW, int NINSTR = NSUB * 16>
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, long ld, int R, int Kend, int r0, int k0,
                                            char* lds_tile, int wave, int lane) {
+  static_assert(NINSTR % NW == 0, "every wave issues the same number of DMA instructions (counted vmcnt waits)");
 #pragma unroll
-  for (int i = 0; i < NSUB * 16 / NW; ++i) {
+  for (int i = 0; i < NINSTR / NW; ++i) {
     const int idx = wave + NW * i;
     const int sub = idx >> 4, rb = idx & 15;
     const bf16* src;
@@ -89,7 +91,9 @@ __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, 
 template <int PERM>
 __device__ __forceinline__ bf16x8 frag_cols(const char* tile, int col0, int nt, int ks, int lane) {
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int col = PERM ? col0 + 8 * p + 32 * (nt >> 1) + 4 * (nt & 1) : col0 + 16 * nt + 4 * p;
+  int col = PERM ? col0 + 8 * p + 32 * (nt >> 1) + 4 * (nt & 1) : col0 + 16 * nt + 4 * p;
+  tile += (col >> 7) * TILE_BYTES;          // a wave's columns may run on into the next 128-column sub-tile (192-row tiles)
+  col &= 127;
   const int chunk = col >> 3, sub = (col & 7) * 2;
   const int kr0 = 32 * ks + 8 * g + q, kr1 = kr0 + 4;
   bf16x4 lo = lds_read_tr16(tile + kr0 * 256 + ((chunk ^ fswz(kr0)) << 4) + sub);
@@ -197,7 +201,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   constexpr int NW = WM * WN, BM_ = 16 * MT * WM, BN_ = 64 * WN;
   constexpr int NSA = (BM_ + 127) / 128, NSB = (BN_ + 127) / 128;   // 128-wide sub-tiles per operand
   constexpr int STAGE_BYTES_ = (NSA + NSB) * TILE_BYTES;
-  constexpr int G = (NSA + NSB) * 16 / NW;                        // DMA instructions per wave per stage
+  // A tiles that do not fill their last 128-row sub-tile (MT = 6: 192 rows) only stage the 8-row groups they use
+  constexpr int AI = (A_KC && (BM_ & 127)) ? ((BM_ / 8 + NW - 1) / NW) * NW : NSA * 16;
+  constexpr int G = (AI + NSB * 16) / NW;                         // DMA instructions per wave per stage
   constexpr int PD = STAGES - 1;                                  // prefetch distance in K-tiles
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES_];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -239,19 +245,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   for (int s = 0; s < PD; ++s) {
     if (kt0 + s < kt1) {
       char* sb = smem + s * STAGE_BYTES_;
-      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt0 + s) * BK, sb, wave, lane);
+      stage_tile<A_KC, 0, NSA, NW, AI>(p.A, p.lda, p.M, p.K, bm0, (kt0 + s) * BK, sb, wave, lane);
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt0 + s) * BK, sb + NSA * TILE_BYTES, wave, lane);
     }
   }
   int cur = 0;                                                   // stage holding tile kt
-  constexpr bool WG_LAYOUT = !A_KC && !B_KC && MT <= 4;     // (the 128x64-per-wave kernels have no registers left for it)
-  // Column order of the B fragments.  The n-permutation (nperm above) exists for the epilogue: a lane then owns runs of 8
-  // consecutive output columns.  Read from a K-STRIDED tile it costs LDS bandwidth: the four 4-column pieces a
-  // ds_read_b64_tr_b16 gathers all sit in the SAME half of their 16-byte chunks, so the 32 lanes of a bank group can only
-  // reach half of the 64 banks - a 2-way conflict on every B read (the DMA image is 16-byte granular: no swizzle fixes it).
-  // The weight-gradient layout (both operands K-strided, contraction over tokens: thousands of K iterations, a negligible
-  // epilogue) therefore reads B in NATURAL column order - conflict-free like A - and has its own 4-column epilogue.
-  constexpr int BPERM = (A_KC || B_KC) ? 1 : 0;
+  constexpr bool WG_LAYOUT = !A_KC && !B_KC && MT <= 6;     // (the 128x64-per-wave kernels have no registers left for it)
+  // (Round 2 measured the B fragments of the weight-gradient layout in NATURAL column order - by the bank model their four
+  // 4-column pieces sit in the same half of their 16-byte chunks, a 2-way conflict per ds_read_b64_tr_b16 - against this
+  // permuted order: no difference, 232.9 -> 235.3 us on the qkv weight gradient.  The permutation stays everywhere.)
+  constexpr int BPERM = 1;
   f32x4 accb[WG_LAYOUT ? MT : 1];
   bf16x8 ones8;
 #pragma unroll
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     // then starts too late to land within one iteration: the 256x256 configuration deals it out between k-step 0's
     // FIRST MFMAs instead (ILV_EARLY, neutral), and the 128x128 one keeps the DMA ahead of the fragment reads.
     constexpr bool ILV = STAGES >= 3 || (MT >= 8 && !(A_KC && B_KC)) || (!A_KC && !B_KC);
-    constexpr bool ILV_EARLY = !ILV && MT >= 8;
+    constexpr bool ILV_EARLY = !ILV && MT >= 6;
     // tile kt has landed for this wave once at most the younger stages' DMAs are outstanding; the barrier then
     // (a) publishes every wave's part of tile kt and (b) proves every wave is done reading stage cur-1
     if (PD >= 3 && wait_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     if (DMA && !ILV && !ILV_EARLY) {
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
-      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
+      stage_tile<A_KC, 0, NSA, NW, AI>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     if (DMA && ILV_EARLY) {   // program order: k-step 0 reads, DMA, k-step 1 reads
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
-      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
+      stage_tile<A_KC, 0, NSA, NW, AI>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
     }
 #pragma unroll
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     if (DMA && ILV) {     // after the fragment reads in program order (the DMA writes LDS: the reads may not sink below it)
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
-      stage_tile<A_KC, 0, NSA, NW>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
+      stage_tile<A_KC, 0, NSA, NW, AI>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
       stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
     }
 #pragma unroll
@@ -404,56 +407,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
         }
     }
   }
-  if constexpr (!BPERM) {
-    // ---- weight-gradient epilogue (natural B columns): lane holds, per (mt, nt), columns n0..n0+3 of row m ----
-    // forms the dispatcher admits for this layout: raw split-K slabs, or alpha*acc (+ bias) (+ fp32 residual) -> fp32 / 16-bit
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = bm0 + wm0 + 16 * mt + li;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n0 = bn0 + wn0 + 16 * nt + 4 * g;
-        if (n0 >= p.N) continue;
-        float v[4] = {acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-        const bool full = n0 + 4 <= p.N;
-        if (p.split_ws) {                                    // (split-K requires N % 4 == 0: always a full run)
-          *(float4*)(p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0) = make_float4(v[0], v[1], v[2], v[3]);
-          continue;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] *= p.alpha;
-          if (p.bias && n0 + r < p.N) v[r] += p.bias[n0 + r];
-        }
-        if (p.residual) {
-          const float* rp = p.residual + (long)m * p.ldr + n0;
-          if (full) { const float4 t = *(const float4*)rp; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-          else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] += rp[r];
-          }
-        }
-        if (p.out_f32) {
-          float* o = p.out_f32 + (long)m * p.ldc + n0;
-          if (full) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-          else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n0 + r < p.N) o[r] = v[r];
-          }
-        }
-        if (p.out_bf16) {
-          bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
-          if (full) { bf16x4 t = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *(bf16x4*)o = t; }
-          else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
-          }
-        }
-      }
-    }
-    return;
-  }
   // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
   // Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then the
   // math and the stores - one memory round trip per batch instead of one per 8-column run.
@@ -533,7 +486,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 template <int WM, int WN, int STAGES, int MT>
 static bool gemm_launch_cfg(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a) {
   dim3 block(64 * WM * WN);
-  if (a.colsum_dst && MT > 4) return false;                 // fused bias gradient: 64x64-per-wave configurations only
+  if (a.colsum_dst && MT > 6) return false;                 // fused bias gradient: not in the 128x64-per-wave configuration (registers)
 #define LAUNCH(AK, BKC, ACTV) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, ACTV, WM, WN, STAGES, MT>), grid, block, 0, stream, a)
   if (lay == 3) {
     switch (act) {
@@ -542,6 +495,8 @@ static bool gemm_launch_cfg(int lay, int act, dim3 grid, hipStream_t stream, con
       case CCLIP_ACT_TANH: LAUNCH(1, 1, CCLIP_ACT_TANH); return true;
       case CCLIP_ACT_RELU: LAUNCH(1, 1, CCLIP_ACT_RELU); return true;
       case CCLIP_ACT_DGELU_NEW: LAUNCH(1, 1, CCLIP_ACT_DGELU_NEW); return true;
+      case CCLIP_ACT_DQUICKGELU: LAUNCH(1, 1, CCLIP_ACT_DQUICKGELU); return true;   // dgrad through transposed weight shadows
+      case CCLIP_ACT_DRELU: LAUNCH(1, 1, CCLIP_ACT_DRELU); return true;
       default: return false;
     }
   } else if (lay == 2) {

@@ -81,6 +81,8 @@ typedef struct cclip_gemm_desc {
                         * 4 = persistent 256x128 with the epilogue streamed under the next tile's K loop - forward layout,
                         *     M % 256 == 0, N % 128 == 0, N <= 4096, K >= 512 (640 with a residual), one of the three
                         *     epilogue forms {16-bit out | pre-activation + activation | fp32 out + residual}; status 1 otherwise.
+                        * 5 = 192x256 (configuration 3's K loop with 96x64 per wave; K-contiguous A only): a tile-count
+                        *     quantisation option - 9.39 rounds of 0.75-size tiles instead of 7.03 rounds of full ones.
                         * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
   /* wgrad layout (0,0) only: colsum_out[m] (+)= sum_k A(m,k) - the BIAS gradient of the layer whose weight gradient this
    * call computes (A = dY^T), taken off the operand tiles already in LDS by one extra MFMA per m-tile against an all-ones

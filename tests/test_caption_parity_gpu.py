@@ -102,10 +102,11 @@ def test_caption_real_geometry_matches_golden(half):
     params = dict(model.named_parameters())
     for k, ref in g["grads"].items():
         assert rel(sample(params[k].grad), ref) < tol["grad"], (k, rel(sample(params[k].grad), ref))
-    for k, nrm in g["grad_norms"].items():
-        if k == "model.lm_head.weight":
-            continue
-        assert abs(params[k].grad.norm().item() - nrm.item()) <= tol["norm"] * nrm.item() + 1e-7, k
+    ratios = {k: params[k].grad.norm().item() / nrm.item() for k, nrm in g["grad_norms"].items() if k != "model.lm_head.weight"}
+    worst = sorted(ratios.items(), key=lambda kv: -abs(kv[1] - 1.0))[:6]
+    print("gradient-norm ratios (HIP / oracle), worst:", [(k, round(v, 4)) for k, v in worst])
+    for k, r in ratios.items():
+        assert abs(r - 1.0) <= tol["norm"], (k, r)
 
 
 def test_caption_bs256_properties():

@@ -57,7 +57,7 @@ LAYOUTS = [(True, True), (True, False), (False, False)]
 SHAPES = [(128, 128, 64), (256, 384, 192), (450, 768, 768), (264, 200, 72), (1000, 2304, 768), (72, 136, 3072)]
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 5])
 @pytest.mark.parametrize("akc,bkc", LAYOUTS)
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_gemm_plain(M, N, K, akc, bkc, cfg):
@@ -78,7 +78,7 @@ def test_gemm_plain(M, N, K, akc, bkc, cfg):
 
 @pytest.mark.parametrize("act,akc,bkc", [(1, True, True), (2, True, True), (4, True, True), (18, True, True),
                                          (3, True, False), (16, True, False), (17, True, False), (19, True, False)])
-@pytest.mark.parametrize("cfg", [0, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5])
 def test_gemm_epilogues(act, akc, bkc, cfg):
     ops = _ops()
     M, N, K = 300, 264, 256
@@ -119,7 +119,7 @@ def test_gemm_residual_inplace_and_ld():
     _report("inplace", x, ref, 2e-3)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 5])
 @pytest.mark.parametrize("splits", [2, 5, 16])
 def test_gemm_wgrad_splitk(splits, cfg):
     """wgrad layout (0,0) with ragged contraction (tokens) and split-K slabs + accumulate into grad."""
@@ -243,7 +243,7 @@ def test_gemm_skinny_decode_shapes(M, N, K, kind, dt):
 
 
 # ---- bias gradient fused into the weight-gradient GEMM (row sums of A over K) ------------------------------------------
-@pytest.mark.parametrize("cfg,split", [(1, 1), (2, 1), (1, 8), (2, 5), (0, 0)])
+@pytest.mark.parametrize("cfg,split", [(1, 1), (2, 1), (1, 8), (2, 5), (5, 1), (5, 7), (0, 0)])
 @pytest.mark.parametrize("n_out,k_in,tokens", [(768, 256, 5000), (2304, 768, 3136), (200, 136, 1000)])
 @pytest.mark.parametrize("conv1d", [False, True])
 def test_wgrad_with_fused_bias_gradient(n_out, k_in, tokens, cfg, split, conv1d):

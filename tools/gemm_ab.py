@@ -60,6 +60,7 @@ if __name__ == "__main__":
               ("img fc infer", Mi, 3072, 768, 1, 1, "bf16"), ("img proj", Mi, 768, 3072, 1, 1, "res"),
               ("txt qkv", Mt, 1536, 512, 1, 1, "bf16"), ("txt out", Mt, 512, 512, 1, 1, "res"), ("txt fc train", Mt, 2048, 512, 1, 1, "gelu"),
               ("txt proj", Mt, 512, 2048, 1, 1, "res"),
+              ("img dgradT fc", Mi, 768, 3072, 1, 1, "bf16"), ("img dgradT proj", Mi, 3072, 768, 1, 1, "dact"), ("img dgradT qkv", Mi, 768, 2304, 1, 1, "bf16"),
               ("img dgrad fc", Mi, 768, 3072, 1, 0, "bf16"), ("img dgrad proj", Mi, 3072, 768, 1, 0, "dact"), ("img dgrad qkv", Mi, 768, 2304, 1, 0, "bf16"),
               ("img wgrad qkv", 2304, 768, Mi, 0, 0, "split"), ("img wgrad proj", 768, 3072, Mi, 0, 0, "split"), ("img wgrad fc", 3072, 768, Mi, 0, 0, "split"),
               ("square 4096", 4096, 4096, 4096, 1, 1, "bf16")]
