@@ -36,6 +36,7 @@ bool cclip_gemm_launch_cfg2(int lay, int act, dim3 grid, hipStream_t stream, con
 bool cclip_gemm_launch_cfg3(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg4(int lay, int act, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg5(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
+bool cclip_gemm_launch_cfg6(int lay, int act, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmArgs& a);
 
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
@@ -137,6 +138,10 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     return cclip_launch_status();
   if (cfg == 4) {     // persistent streaming-epilogue kernel: forward layout, full tiles only - refused (not silently replaced) otherwise
     if (splits > 1 || !cclip_gemm_launch_cfg4(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
+    return cclip_launch_status();
+  }
+  if (cfg == 6) {     // persistent 192x256 with the finished tile parked in 16 bits and streamed under the next K loop - refused otherwise
+    if (splits > 1 || !cclip_gemm_launch_cfg6(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
     return cclip_launch_status();
   }
   if (cfg <= 0 || cfg > 5) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);

@@ -1,0 +1,262 @@
+// tile configuration 6 ("streaming 192x256"): PERSISTENT workgroups with the K loop of configuration 5 (8 waves of 96x64,
+// two 56 KiB LDS stages) whose finished tile is written out UNDER THE NEXT TILE'S K LOOP.
+//
+// Why: on the model's shapes (K = 512 / 768) a tile's epilogue is not hidden by anything - a CU moves its 96-384 KiB of
+// outputs at ~15 B/clk while its matrix pipe idles, the same on every CU at the same time - and costs 25-40 % of the launch
+// (round-2 A/B: the fc projection with its two 16-bit outputs takes 327 us, with one 268 us).
+// Configuration 4 already streams the epilogue, but keeps the finished tile as a second fp32 accumulator set, which only
+// fits 64x64 wave tiles, whose K iteration is LDS-bound; it never beat configuration 3 on the large projections.
+// Here the finished tile is PARKED as packed 16-bit values (96 accumulators -> 48 registers; bias already added): with the
+// 96x64 wave tile the kernel needs 186 + 48 registers.  One 8-column run per lane (one 16-byte store; two for the
+// pre-activation + activation form) leaves per K iteration of the following tile, interleaved with its MFMAs.
+//
+// Epilogue forms (forward operand layout only; with the transposed weight shadows that covers the dgrad GEMMs too):
+//   EPI 0: out16 = alpha*acc + bias                                  (qkv projection, dgrad outputs)
+//   EPI 1: pre16 = alpha*acc + bias;  out16 = ACT(pre16 as stored)   (training fc: the activation is evaluated on the
+//          ROUNDED pre-activation in every tile configuration, so all of them produce the same bits)
+// vmcnt bookkeeping: one in-order counter per wave holds the operand DMA and the stores.  Per iteration the order is fixed:
+// DMA group of K-tile kt+1, then the streamed stores; the wait for K-tile kt+1 at the top of the next iteration leaves
+// exactly the stores issued after that group in flight (counted), i.e. a store has one full iteration to retire.
+#include "gemm_bf16_impl.h"
+
+namespace CCLIP_NS {
+
+// LDS-DMA with a SCALAR base and a 32-bit per-lane offset: `global_load_lds_dwordx4 voff, s[base:base+1]`.  The per-lane
+// part of an operand address (row * ld + swizzled 16-byte chunk) never changes during the launch - every tile origin and
+// K offset is workgroup-uniform - so each wave keeps 7 offset registers for the whole kernel and a K-tile's DMA group is
+// 7 x (s_mov m0, load) plus two scalar adds, instead of ~200 address instructions per iteration.
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_off) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+
+template <int EPI, int ACT, int CPI>
+__global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, int ntiles) {
+  constexpr int MT = 6, BM_ = 192, BN_ = 256, STAGES = 2;
+  constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE_BYTES_ = A_BYTES + B_BYTES;     // 24 + 32 = 56 KiB
+  constexpr int G = (BM_ / 8 + BN_ / 8) / 8;                      // 7 DMA instructions per wave per stage
+  constexpr int S = EPI == 1 ? 2 : 1;                             // stores per streamed chunk
+  constexpr int NCH = 2 * MT;                                     // 12 chunks (m-tile, half) per tile
+  constexpr int NPOS = NCH / CPI;                                 // unrolled positions per tile
+  __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES_ + 4096 * 4];
+  float* bias_s = (float*)(smem + STAGES * STAGE_BYTES_);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = p.N / BN_;
+  const int KT = (p.K + BK - 1) / BK;
+  const int nwg = gridDim.x;
+  const int wq = xcd_remap(blockIdx.x, nwg);
+  const int nmine = (ntiles - wq + nwg - 1) / nwg;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int wm0 = wm * 96, wn0 = wn * 64;
+  const int li = lane & 15, g = lane >> 4;
+
+  for (int i = tid; i < p.N; i += 512) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+
+  // ---- operand DMA: per-lane byte offsets (constant), scalar bases (tile origin + K offset) ----
+  // instruction idx = wave + 8 i covers LDS rows 8 idx .. 8 idx + 7 (128 B each); lane -> (row, 16-byte slot), the slot holds
+  // logical chunk (lane & 7) ^ (row & 7); B rows are stored n-permuted (nperm) so fragment reads stay natural
+  unsigned offA[BM_ / 64], offB[BN_ / 64];
+#pragma unroll
+  for (int i = 0; i < BM_ / 64; ++i) {
+    const int rp = (wave + 8 * i) * 8 + (lane >> 3);
+    offA[i] = (unsigned)(rp * p.lda + (((lane & 7) ^ (rp & 7)) << 3)) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < BN_ / 64; ++i) {
+    const int rp = (wave + 8 * i) * 8 + (lane >> 3);
+    const int r = (rp & ~63) + nperm((rp >> 4) & 3, rp & 15);
+    offB[i] = (unsigned)(r * p.ldb + (((lane & 7) ^ (rp & 7)) << 3)) * 2u;
+  }
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)wave * 1024u;
+  // the last row tile is anchored at M - 192: it overlaps its predecessor (those rows are computed twice, bit-identically)
+  // instead of running past M, so no load is clamped and no store is predicated
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    m0 = (t / tiles_n) * BM_; if (m0 > p.M - BM_) m0 = p.M - BM_;
+    n0 = (t % tiles_n) * BN_;
+  };
+  // ---- operand DMA cursor: one K-tile ahead of the multiply, across tile boundaries ----
+  int ij = 0, ikt = 0, istage = 0;
+  int ibm0, ibn0;
+  tile_origin(wq, ibm0, ibn0);
+  auto issue_one = [&]() {
+    const bf16* ga = p.A + (long)ibm0 * p.lda + ikt * BK;
+    const bf16* gb = p.B + (long)ibn0 * p.ldb + ikt * BK;
+    const unsigned la = lds0 + (unsigned)istage * STAGE_BYTES_;
+#pragma unroll
+    for (int i = 0; i < BM_ / 64; ++i) glds16_s(offA[i], ga, la + i * 8192u);
+#pragma unroll
+    for (int i = 0; i < BN_ / 64; ++i) glds16_s(offB[i], gb, la + A_BYTES + i * 8192u);
+    istage ^= 1;
+    if (++ikt == KT) {
+      ikt = 0;
+      if (ij + 1 < nmine) {        // past the last tile the cursor re-stages that tile: nobody reads it, counts stay uniform
+        ++ij;
+        tile_origin(wq + ij * nwg, ibm0, ibn0);
+      }
+    }
+  };
+
+  f32x4 acc[MT][4];
+  bf16x4 park[MT][4];                                             // the previous tile: alpha*acc + bias, rounded to 16 bits
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      park[i][j] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    }
+
+  int bm0 = ibm0, bn0 = ibn0, pbm0 = 0, pbn0 = 0;                // current / previous tile origin
+  issue_one();
+  int cur = 0;
+
+  // stores of chunk c = (m-tile c >> 1, half c & 1) of the PREVIOUS tile: the lane's 8-column run n0..n0+7 of row m
+  auto write_chunk = [&](auto ctag) {
+    constexpr int C = decltype(ctag)::value;
+    constexpr int mt = C >> 1, h = C & 1;
+    const int m = pbm0 + wm0 + 16 * mt + li;
+    const int n0 = pbn0 + wn0 + 32 * h + 8 * g;
+    const bf16x8 t = __builtin_shufflevector(park[mt][2 * h], park[mt][2 * h + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+    if (EPI == 1) {
+      *(bf16x8*)(p.out_pre + (long)m * p.ldc + n0) = t;
+      bf16x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = (bf16)act_apply<ACT>((float)t[r], 0.f);
+      *(bf16x8*)(p.out_bf16 + (long)m * p.ldc + n0) = o;
+    } else {
+      *(bf16x8*)(p.out_bf16 + (long)m * p.ldc + n0) = t;
+    }
+  };
+
+  // One K iteration.  POS = unrolled position inside a tile whose predecessor is being streamed out (-1: no streaming)
+  // WAITN: stores issued after the DMA group of the PREVIOUS iteration (they may stay in flight across this wait)
+  auto k_iter = [&](auto pos_tag, auto wait_tag) {
+    constexpr int POS = decltype(pos_tag)::value;
+    constexpr int WAITN = decltype(wait_tag)::value;
+    constexpr bool ST = POS >= 0 && POS < NPOS;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+    const char* At = smem + cur * STAGE_BYTES_;
+    const char* Bt = At + A_BYTES;
+    bf16x8 xf[2][MT], wf[2][4];
+    // program order: k-step 0's fragment reads, the DMA group of K-tile kt+1 (inline asm: fixed in place), k-step 1's reads
+    // (dealt out between k-step 0's MFMAs below).  The reads of k-step 0 are in flight while the DMA instructions issue.
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[0][mt] = frag_rows(At, wm0 + 16 * mt, 0, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[0][nt] = frag_rows(Bt, wn0 + 16 * nt, 0, lane);
+    issue_one();                                                  // into the stage every wave left before this barrier
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[1][mt] = frag_rows(At, wm0 + 16 * mt, 1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[1][nt] = frag_rows(Bt, wn0 + 16 * nt, 1, lane);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[0][nt], xf[0][mt], acc[mt][nt]);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1's MFMAs carry the streamed chunk(s): conversion / activation VALU and the stores
+    if (ST) {
+      write_chunk(std::integral_constant<int, (ST ? CPI * POS : 0)>{});
+      if (CPI == 2) write_chunk(std::integral_constant<int, (ST ? CPI * POS + CPI - 1 : 0)>{});
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[1][nt], xf[1][mt], acc[mt][nt]);
+    if (ST) {
+      if (EPI == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6 * CPI, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < S * CPI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    cur ^= 1;
+  };
+#define KI(POSV, WAITV) k_iter(std::integral_constant<int, (POSV)>{}, std::integral_constant<int, (WAITV)>{})
+  constexpr int SC = S * CPI;                                    // stores per streaming iteration
+
+  for (int j = 0; j < nmine; ++j) {
+    if (j == 0) {
+      for (int kt = 0; kt < KT; ++kt) KI(-1, 0);
+    } else {
+      // position 0 follows the previous tile's LAST iteration: a streaming one only if that tile streamed through its end
+      if (j >= 2 && KT == NPOS) KI(0, SC); else KI(0, 0);
+      KI(1, SC); KI(2, SC); KI(3, SC); KI(4, SC); KI(5, SC);
+      if (NPOS > 6) { KI(NPOS > 6 ? 6 : 1, SC); KI(NPOS > 6 ? 7 : 1, SC); KI(NPOS > 6 ? 8 : 1, SC); KI(NPOS > 6 ? 9 : 1, SC);
+                      KI(NPOS > 6 ? 10 : 1, SC); KI(NPOS > 6 ? 11 : 1, SC); }
+      if (KT > NPOS) {
+        KI(-1, SC);
+        for (int kt = NPOS + 1; kt < KT; ++kt) KI(-1, 0);
+      }
+    }
+    // tile j is complete: park it (alpha, bias, rounding) - it is streamed out during the next tile's K loop
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n0 = bn0 + wn0 + 32 * h + 8 * g;
+      const float4 b0 = *(const float4*)(bias_s + n0), b1 = *(const float4*)(bias_s + n0 + 4);
+      const float bl[4] = {b0.x, b0.y, b0.z, b0.w}, bh[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        bf16x4 lo, hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[r] = (bf16)(acc[mt][2 * h][r] * p.alpha + bl[r]);
+          hi[r] = (bf16)(acc[mt][2 * h + 1][r] * p.alpha + bh[r]);
+        }
+        park[mt][2 * h] = lo; park[mt][2 * h + 1] = hi;
+        acc[mt][2 * h] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][2 * h + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    pbm0 = bm0; pbn0 = bn0;
+    if (j + 1 < nmine) tile_origin(wq + (j + 1) * nwg, bm0, bn0);
+  }
+  // ---- the last tile has no successor to hide under: plain stores ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  write_chunk(std::integral_constant<int, 0>{}); write_chunk(std::integral_constant<int, 1>{});
+  write_chunk(std::integral_constant<int, 2>{}); write_chunk(std::integral_constant<int, 3>{});
+  write_chunk(std::integral_constant<int, 4>{}); write_chunk(std::integral_constant<int, 5>{});
+  write_chunk(std::integral_constant<int, 6>{}); write_chunk(std::integral_constant<int, 7>{});
+  write_chunk(std::integral_constant<int, 8>{}); write_chunk(std::integral_constant<int, 9>{});
+  write_chunk(std::integral_constant<int, 10>{}); write_chunk(std::integral_constant<int, 11>{});
+}
+
+// Supported: forward layout, N % 256 == 0, N <= 4096, K % 64 == 0 and K >= 384 (the streaming window must end before the
+// tile does: 6 iterations at two chunks per iteration, 12 at one), any M >= 192 (the last row tile is anchored at M - 192), 16-byte aligned 16-bit outputs; no aux / residual / fp32 output / split-K.
+bool cclip_gemm_launch_cfg6(int lay, int act, hipStream_t stream, const GemmArgs& a) {
+  if (lay != 3 || a.split_ws || a.aux || a.residual || a.out_f32 || !a.out_bf16) return false;
+  if ((a.N & 255) || a.N > 4096 || (a.K & 63) || (a.ldc & 7)) return false;
+  const int kt = a.K / BK;
+  if (kt < 6) return false;
+  const int epi = a.out_pre ? 1 : 0;
+  if (epi == 0 && act != CCLIP_ACT_NONE) return false;
+  if (epi == 1 && act != CCLIP_ACT_QUICKGELU) return false;
+  if (a.M < 192 || (a.lda & 7) || (a.ldb & 7)) return false;
+  if ((size_t)192 * a.lda * 2 >= (1ull << 31) || (size_t)256 * a.ldb * 2 >= (1ull << 31)) return false;   // 32-bit DMA offsets
+  const int ntiles = ((a.M + 191) / 192) * (a.N / 256);
+  const int grid = ntiles < 256 ? ntiles : 256;
+  dim3 block(512);
+#define L6(E, ACTV, C) hipLaunchKernelGGL((gemm_stream6_kernel<E, ACTV, C>), dim3(grid), block, 0, stream, a, ntiles)
+  if (kt >= 12) { if (epi == 1) L6(1, CCLIP_ACT_QUICKGELU, 1); else L6(0, CCLIP_ACT_NONE, 1); }
+  else { if (epi == 1) L6(1, CCLIP_ACT_QUICKGELU, 2); else L6(0, CCLIP_ACT_NONE, 2); }
+#undef L6
+  return true;
+}
+
+}  // namespace CCLIP_NS
