@@ -75,14 +75,15 @@ def _run(**env):
 
 
 @pytest.mark.timeout(1500)
-def test_one_rank_rccl_step_equals_plain_step():
+def test_one_rank_rccl_step_equals_plain_step(tmp_path):
     port = 29700 + (os.getpid() % 200)
-    plain = _run(USE_DP=0)
-    rccl = _run(USE_DP=1, CCLIP_DP_FORCE_COLLECTIVES=1, PORT=port)
+    tune = str(tmp_path / "tune.json")           # all runs share one tuned tile table: same tiles, same summation order
+    plain = _run(USE_DP=0, CCLIP_TUNE_FILE=tune)
+    rccl = _run(USE_DP=1, CCLIP_DP_FORCE_COLLECTIVES=1, PORT=port, CCLIP_TUNE_FILE=tune)
     assert rccl["buckets"] > 4 and min(rccl["early"]) >= 3, rccl        # most buckets were reduced from inside backward
     assert plain["early"] == [0, 0]
     assert rccl["loss"] == plain["loss"] and rccl["grads"] == plain["grads"] and rccl["params"] == plain["params"], (plain, rccl)
     assert abs(rccl["te_grad"] - plain["te_grad"]) <= 1e-6 * plain["te_grad"] and abs(rccl["te_param"] - plain["te_param"]) <= 1e-7 * plain["te_param"]
-    wire = _run(USE_DP=1, CCLIP_DP_FORCE_COLLECTIVES=1, PORT=port + 1, WIRE16=1)       # bf16 gradient buckets on the wire
+    wire = _run(USE_DP=1, CCLIP_DP_FORCE_COLLECTIVES=1, PORT=port + 1, WIRE16=1, CCLIP_TUNE_FILE=tune)   # bf16 gradient buckets on the wire
     assert wire["loss"] == plain["loss"]                                 # (step 2's loss still comes from fp32-reduced step 1? no:
     assert abs(wire["logit_scale"] - plain["logit_scale"]) < 1e-5        #  parameters differ by the bf16 rounding of the gradients)

@@ -13,10 +13,10 @@ run() {  # tag, shape, cfg
     rocprofv3 --pmc $C --output-format csv -d $OUT/$1_p$pass -- python3 $R/tools/gemm_one.py "$2" $3 3 > $OUT/$1_p$pass.log 2>&1 || echo "pass failed: $1 $pass"
   done
 }
-run qkv_cfg3 "img qkv" 3
-run qkv_cfg4 "img qkv" 4
-run qkv_cfg5 "img qkv" 5
-run sq_cfg3 "square 4096" 3
-run wgrad_cfg2 "img wgrad qkv" 2
-run fctrain_cfg3 "img fc train" 3
+
+IFS=$'\n'
+for spec in $(echo "${PMC_RUNS:-qkv_cfg5|img qkv|5;qkv_cfg6|img qkv|6;fctrain_cfg6|img fc train|6}" | tr ';' '\n'); do
+  tag=$(echo "$spec" | cut -d'|' -f1); shape=$(echo "$spec" | cut -d'|' -f2); cfg=$(echo "$spec" | cut -d'|' -f3)
+  run "$tag" "$shape" "$cfg"
+done
 echo done
