@@ -14,9 +14,13 @@
 //   EPI 0: out16 = alpha*acc + bias                                  (qkv projection, dgrad outputs)
 //   EPI 1: pre16 = alpha*acc + bias;  out16 = ACT(pre16 as stored)   (training fc: the activation is evaluated on the
 //          ROUNDED pre-activation in every tile configuration, so all of them produce the same bits)
-// vmcnt bookkeeping: one in-order counter per wave holds the operand DMA and the stores.  Per iteration the order is fixed:
-// DMA group of K-tile kt+1, then the streamed stores; the wait for K-tile kt+1 at the top of the next iteration leaves
-// exactly the stores issued after that group in flight (counted), i.e. a store has one full iteration to retire.
+// vmcnt: a wave has ONE in-order counter for its LDS-DMA and its stores, so "my DMA has landed" also means "every older store
+// of mine has been acknowledged".  Measured (round 2, PMC): with every wave issuing both each iteration a store had less
+// than one iteration to retire and the DMA waits grew by ~900 clocks per iteration (267 vs 225 us on the qkv projection).
+// The two wave groups (waves 0-3 / 4-7) therefore ALTERNATE roles: in an even iteration group A issues the whole DMA group
+// of the next K-tile (14 instructions per wave) while group B issues its streamed stores (two iterations' worth), in an
+// odd iteration the other way round.  A wave waits (vmcnt(0)) only at the top of the iteration after its DMA turn - by
+// then its last stores are ~1.5 iterations old - and never carries a store across its own DMA wait window.
 #include "gemm_bf16_impl.h"
 
 namespace CCLIP_NS {
@@ -33,16 +37,17 @@ template <int EPI, int ACT, int CPI>
 __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, int ntiles) {
   constexpr int MT = 6, BM_ = 192, BN_ = 256, STAGES = 2;
   constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE_BYTES_ = A_BYTES + B_BYTES;     // 24 + 32 = 56 KiB
-  constexpr int G = (BM_ / 8 + BN_ / 8) / 8;                      // 7 DMA instructions per wave per stage
-  constexpr int S = EPI == 1 ? 2 : 1;                             // stores per streamed chunk
   constexpr int NCH = 2 * MT;                                     // 12 chunks (m-tile, half) per tile
-  constexpr int NPOS = NCH / CPI;                                 // unrolled positions per tile
+  constexpr int NPOS = NCH / CPI;                                 // iterations of the streaming window (12 or 6)
+  constexpr int CPS = 2 * CPI;                                    // chunks per store turn (a wave stores every other iteration)
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES_ + 4096 * 4];
   float* bias_s = (float*)(smem + STAGES * STAGE_BYTES_);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool grpA = wave < 4;
+  const int w4 = wave & 3;
   const int tiles_n = p.N / BN_;
-  const int KT = (p.K + BK - 1) / BK;
+  const int KT = p.K / BK;                                        // even (host-checked): role parity is the same in every tile
   const int nwg = gridDim.x;
   const int wq = xcd_remap(blockIdx.x, nwg);
   const int nmine = (ntiles - wq + nwg - 1) / nwg;
@@ -53,48 +58,46 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
   for (int i = tid; i < p.N; i += 512) bias_s[i] = p.bias ? p.bias[i] : 0.f;
   __syncthreads();
 
-  // ---- operand DMA: per-lane byte offsets (constant), scalar bases (tile origin + K offset) ----
-  // instruction idx = wave + 8 i covers LDS rows 8 idx .. 8 idx + 7 (128 B each); lane -> (row, 16-byte slot), the slot holds
-  // logical chunk (lane & 7) ^ (row & 7); B rows are stored n-permuted (nperm) so fragment reads stay natural
-  unsigned offA[BM_ / 64], offB[BN_ / 64];
-#pragma unroll
-  for (int i = 0; i < BM_ / 64; ++i) {
-    const int rp = (wave + 8 * i) * 8 + (lane >> 3);
-    offA[i] = (unsigned)(rp * p.lda + (((lane & 7) ^ (rp & 7)) << 3)) * 2u;
-  }
-#pragma unroll
-  for (int i = 0; i < BN_ / 64; ++i) {
-    const int rp = (wave + 8 * i) * 8 + (lane >> 3);
-    const int r = (rp & ~63) + nperm((rp >> 4) & 3, rp & 15);
-    offB[i] = (unsigned)(r * p.ldb + (((lane & 7) ^ (rp & 7)) << 3)) * 2u;
-  }
-  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)wave * 1024u;
+  // ---- operand DMA: instruction idx = w4 + 4 i (i < 6 for A, < 8 for B) of the issuing group covers LDS rows
+  // 8 idx .. 8 idx + 7; lane -> row rp = 8 w4 + (lane >> 3) + 32 i and 16-byte slot lane & 7, holding logical chunk
+  // (lane & 7) ^ (rp & 7).  rp & 7 does not depend on i, and the n-permuted source row of a B position is 32 i + a lane
+  // constant too (nperm is affine in the 32-row block index) - so ONE byte offset per operand and lane serves every
+  // instruction, the rest (32 i rows, tile origin, K offset) is scalar.
+  const int rlow = 8 * w4 + (lane >> 3);                          // 0..31
+  const unsigned swz = (unsigned)(((lane & 7) ^ (rlow & 7)) << 4);
+  const unsigned offA = (unsigned)rlow * (unsigned)p.lda * 2u + swz;
+  const unsigned offB = (unsigned)nperm(rlow >> 4, rlow & 15) * (unsigned)p.ldb * 2u + swz;
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)w4 * 1024u;
+  const unsigned strideA = 64u * (unsigned)p.lda, strideB = 64u * (unsigned)p.ldb;   // bytes per 32-row block
   // the last row tile is anchored at M - 192: it overlaps its predecessor (those rows are computed twice, bit-identically)
   // instead of running past M, so no load is clamped and no store is predicated
   auto tile_origin = [&](int t, int& m0, int& n0) {
     m0 = (t / tiles_n) * BM_; if (m0 > p.M - BM_) m0 = p.M - BM_;
     n0 = (t % tiles_n) * BN_;
   };
-  // ---- operand DMA cursor: one K-tile ahead of the multiply, across tile boundaries ----
+  // ---- operand DMA cursor: one K-tile ahead of the multiply, across tile boundaries (advanced by every wave alike) ----
   int ij = 0, ikt = 0, istage = 0;
   int ibm0, ibn0;
   tile_origin(wq, ibm0, ibn0);
-  auto issue_one = [&]() {
-    const bf16* ga = p.A + (long)ibm0 * p.lda + ikt * BK;
-    const bf16* gb = p.B + (long)ibn0 * p.ldb + ikt * BK;
-    const unsigned la = lds0 + (unsigned)istage * STAGE_BYTES_;
-#pragma unroll
-    for (int i = 0; i < BM_ / 64; ++i) glds16_s(offA[i], ga, la + i * 8192u);
-#pragma unroll
-    for (int i = 0; i < BN_ / 64; ++i) glds16_s(offB[i], gb, la + A_BYTES + i * 8192u);
+  auto cursor_advance = [&]() {
     istage ^= 1;
     if (++ikt == KT) {
       ikt = 0;
-      if (ij + 1 < nmine) {        // past the last tile the cursor re-stages that tile: nobody reads it, counts stay uniform
+      if (ij + 1 < nmine) {        // past the last tile the cursor re-stages that tile: nobody reads it
         ++ij;
         tile_origin(wq + ij * nwg, ibm0, ibn0);
       }
     }
+  };
+  auto issue_group = [&]() {       // the whole stage: 14 instructions per wave of the issuing group
+    const bf16* ga = p.A + (long)ibm0 * p.lda + ikt * BK;
+    const bf16* gb = p.B + (long)ibn0 * p.ldb + ikt * BK;
+    const unsigned la = lds0 + (unsigned)istage * STAGE_BYTES_;
+    unsigned va = offA, vb = offB;             // running per-lane offsets (one VALU add per instruction, one scalar base each)
+#pragma unroll
+    for (int i = 0; i < BM_ / 32; ++i) { glds16_s(va, ga, la + i * 4096u); va += strideA; }
+#pragma unroll
+    for (int i = 0; i < BN_ / 32; ++i) { glds16_s(vb, gb, la + A_BYTES + i * 4096u); vb += strideB; }
   };
 
   f32x4 acc[MT][4];
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
     }
 
   int bm0 = ibm0, bn0 = ibn0, pbm0 = 0, pbn0 = 0;                // current / previous tile origin
-  issue_one();
+  if (!grpA) issue_group();                                       // K-tile 0: by the group that waits at the top of iteration 0
+  cursor_advance();
   int cur = 0;
 
   // stores of chunk c = (m-tile c >> 1, half c & 1) of the PREVIOUS tile: the lane's 8-column run n0..n0+7 of row m
@@ -129,23 +133,25 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
     }
   };
 
-  // One K iteration.  POS = unrolled position inside a tile whose predecessor is being streamed out (-1: no streaming)
-  // WAITN: stores issued after the DMA group of the PREVIOUS iteration (they may stay in flight across this wait)
-  auto k_iter = [&](auto pos_tag, auto wait_tag) {
-    constexpr int POS = decltype(pos_tag)::value;
-    constexpr int WAITN = decltype(wait_tag)::value;
-    constexpr bool ST = POS >= 0 && POS < NPOS;
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+  // One K iteration.  PAR = parity of the iteration inside its tile (KT is even).  The ISSUER group of this iteration
+  // (group A in even ones) puts the whole DMA group of the next K-tile in flight; the other group issued the DMA of the
+  // K-tile being multiplied now: it waits for it (vmcnt(0): its last stores are ~1.5 iterations old by then) and - inside a
+  // streaming window (TURN >= 0) - writes chunks [CPS*TURN, CPS*TURN + CPS) of the previous tile.  Role tests are scalar
+  // branches around three small blocks; the MFMA / fragment-read schedule is one path for both roles.
+  auto k_iter = [&](auto par_tag, auto turn_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr int TURN = decltype(turn_tag)::value;
+    const bool issuer = grpA == (PAR == 0);
+    if (!issuer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
     const char* At = smem + cur * STAGE_BYTES_;
     const char* Bt = At + A_BYTES;
     bf16x8 xf[2][MT], wf[2][4];
-    // program order: k-step 0's fragment reads, the DMA group of K-tile kt+1 (inline asm: fixed in place), k-step 1's reads
-    // (dealt out between k-step 0's MFMAs below).  The reads of k-step 0 are in flight while the DMA instructions issue.
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xf[0][mt] = frag_rows(At, wm0 + 16 * mt, 0, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) wf[0][nt] = frag_rows(Bt, wn0 + 16 * nt, 0, lane);
-    issue_one();                                                  // into the stage every wave left before this barrier
+    if (issuer) issue_group();       // inline asm, fixed in place: k-step 0's reads are in flight while the DMA issues
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xf[1][mt] = frag_rows(At, wm0 + 16 * mt, 1, lane);
@@ -156,55 +162,43 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[0][nt], xf[0][mt], acc[mt][nt]);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < 10; ++i) {                                // k-step 0's MFMAs carry k-step 1's fragment reads
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // k-step 1's MFMAs carry the streamed chunk(s): conversion / activation VALU and the stores
-    if (ST) {
-      write_chunk(std::integral_constant<int, (ST ? CPI * POS : 0)>{});
-      if (CPI == 2) write_chunk(std::integral_constant<int, (ST ? CPI * POS + CPI - 1 : 0)>{});
+    if (TURN >= 0 && !issuer) {                                   // the streamed chunks of this group's store turn
+      write_chunk(std::integral_constant<int, (TURN >= 0 ? CPS * TURN : 0)>{});
+      write_chunk(std::integral_constant<int, (TURN >= 0 ? CPS * TURN + 1 : 0)>{});
+      if (CPS == 4) {
+        write_chunk(std::integral_constant<int, (TURN >= 0 && CPS == 4 ? CPS * TURN + 2 : 0)>{});
+        write_chunk(std::integral_constant<int, (TURN >= 0 && CPS == 4 ? CPS * TURN + 3 : 0)>{});
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[1][nt], xf[1][mt], acc[mt][nt]);
-    if (ST) {
-      if (EPI == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 6 * CPI, 0);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < S * CPI; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-      }
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
     __builtin_amdgcn_sched_barrier(0);
+    cursor_advance();
     cur ^= 1;
   };
-#define KI(POSV, WAITV) k_iter(std::integral_constant<int, (POSV)>{}, std::integral_constant<int, (WAITV)>{})
-  constexpr int SC = S * CPI;                                    // stores per streaming iteration
+  // iteration pair (even, odd): group B stores turn T in the even iteration, group A in the odd one
+#define PAIR(T)                                                                     \
+  do {                                                                              \
+    k_iter(std::integral_constant<int, 0>{}, std::integral_constant<int, (T)>{});   \
+    k_iter(std::integral_constant<int, 1>{}, std::integral_constant<int, (T)>{});   \
+  } while (0)
 
   for (int j = 0; j < nmine; ++j) {
     if (j == 0) {
-      for (int kt = 0; kt < KT; ++kt) KI(-1, 0);
+      for (int kt = 0; kt < KT; kt += 2) PAIR(-1);
     } else {
-      // position 0 follows the previous tile's LAST iteration: a streaming one only if that tile streamed through its end
-      if (j >= 2 && KT == NPOS) KI(0, SC); else KI(0, 0);
-      KI(1, SC); KI(2, SC); KI(3, SC); KI(4, SC); KI(5, SC);
-      if (NPOS > 6) { KI(NPOS > 6 ? 6 : 1, SC); KI(NPOS > 6 ? 7 : 1, SC); KI(NPOS > 6 ? 8 : 1, SC); KI(NPOS > 6 ? 9 : 1, SC);
-                      KI(NPOS > 6 ? 10 : 1, SC); KI(NPOS > 6 ? 11 : 1, SC); }
-      if (KT > NPOS) {
-        KI(-1, SC);
-        for (int kt = NPOS + 1; kt < KT; ++kt) KI(-1, 0);
-      }
+      PAIR(0); PAIR(1); PAIR(2);
+      if (NPOS > 6) { PAIR(NPOS > 6 ? 3 : 0); PAIR(NPOS > 6 ? 4 : 0); PAIR(NPOS > 6 ? 5 : 0); }
+      for (int kt = NPOS; kt < KT; kt += 2) PAIR(-1);
     }
     // tile j is complete: park it (alpha, bias, rounding) - it is streamed out during the next tile's K loop
 #pragma unroll
@@ -227,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
     pbm0 = bm0; pbn0 = bn0;
     if (j + 1 < nmine) tile_origin(wq + (j + 1) * nwg, bm0, bn0);
   }
+#undef PAIR
   // ---- the last tile has no successor to hide under: plain stores ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   write_chunk(std::integral_constant<int, 0>{}); write_chunk(std::integral_constant<int, 1>{});
@@ -237,11 +232,11 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
   write_chunk(std::integral_constant<int, 10>{}); write_chunk(std::integral_constant<int, 11>{});
 }
 
-// Supported: forward layout, N % 256 == 0, N <= 4096, K % 64 == 0 and K >= 384 (the streaming window must end before the
+// Supported: forward layout, N % 256 == 0, N <= 4096, K % 128 == 0 and K >= 384 (the streaming window must end before the
 // tile does: 6 iterations at two chunks per iteration, 12 at one), any M >= 192 (the last row tile is anchored at M - 192), 16-byte aligned 16-bit outputs; no aux / residual / fp32 output / split-K.
 bool cclip_gemm_launch_cfg6(int lay, int act, hipStream_t stream, const GemmArgs& a) {
   if (lay != 3 || a.split_ws || a.aux || a.residual || a.out_f32 || !a.out_bf16) return false;
-  if ((a.N & 255) || a.N > 4096 || (a.K & 63) || (a.ldc & 7)) return false;
+  if ((a.N & 255) || a.N > 4096 || (a.K & 127) || (a.ldc & 7)) return false;   // (an even number of K-tiles: the role parity)
   const int kt = a.K / BK;
   if (kt < 6) return false;
   const int epi = a.out_pre ? 1 : 0;

@@ -66,7 +66,7 @@ def clip_case(name: str, n: int, seed: int, with_grads: bool):
         loss, _ = O.contrastive_loss(li, lt)
         loss.backward()
         out["grads"] = {k: sample(sdg[k].grad) for k in GRAD_KEYS}
-        out["grad_norms"] = {k: sdg[k].grad.norm() for k in sdg}
+        out["grad_norms"] = {k: sdg[k].grad.double().norm().float() for k in sdg}
     return out
 
 
@@ -97,7 +97,7 @@ def caption_case(name: str, b: int, lc: int, seed: int):
     return dict(model=name, seed=seed, b=b, lc=lc, mapper_out=sample(mapped, 8192),
                 logits_slice=sample(logits.detach()[:, geo.prefix_length + geo.attribute_length - 1:-1], 8192),
                 loss=loss.detach(), grads={k: sample(sdg[k].grad) for k in keys},
-                grad_norms={k: v.grad.norm() for k, v in sdg.items() if v.grad is not None})
+                grad_norms={k: v.grad.double().norm().float() for k, v in sdg.items() if v.grad is not None})
 
 
 def caption_tmapper_case(name: str, b: int, lc: int, seed: int, clip_length: int, num_layers: int):
@@ -116,7 +116,7 @@ def caption_tmapper_case(name: str, b: int, lc: int, seed: int, clip_length: int
     keys = [k for k in sdg if k.startswith("clip_project.") and (".layers.0." in k or ".layers.1.attn" in k or "linear" in k or "prefix_const" in k)]
     return dict(model=name, seed=seed, b=b, lc=lc, clip_length=clip_length, num_layers=num_layers, mapper_out=sample(mapped, 8192),
                 loss=loss.detach(), grads={k: sample(sdg[k].grad) for k in keys},
-                grad_norms={k: v.grad.norm() for k, v in sdg.items() if v.grad is not None and k.startswith("clip_project.")})
+                grad_norms={k: v.grad.double().norm().float() for k, v in sdg.items() if v.grad is not None and k.startswith("clip_project.")})
 
 
 CASES = {

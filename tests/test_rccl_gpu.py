@@ -59,8 +59,9 @@ def digest(flat):
 
 
 (gh, gte), (ph, pte) = digest(ar.gflat), digest(ar.flat)
+per = {n: hashlib.sha256(ar.g[n].cpu().numpy().tobytes()).hexdigest()[:12] for n in ar.names if n != "token_embedding.weight"}
 out = dict(loss=loss.item().hex(), params=ph, grads=gh, te_grad=gte, te_param=pte, early=early, buckets=len(red.buckets),
-           logit_scale=model.logit_scale.item())
+           logit_scale=model.logit_scale.item(), per=per, misses=__import__("cclip_hip").ops._TUNE_STATE["misses"])
 if use_dp:
     dist.destroy_process_group()
 print(json.dumps(out))
@@ -82,7 +83,9 @@ def test_one_rank_rccl_step_equals_plain_step(tmp_path):
     rccl = _run(USE_DP=1, CCLIP_DP_FORCE_COLLECTIVES=1, PORT=port, CCLIP_TUNE_FILE=tune)
     assert rccl["buckets"] > 4 and min(rccl["early"]) >= 3, rccl        # most buckets were reduced from inside backward
     assert plain["early"] == [0, 0]
-    assert rccl["loss"] == plain["loss"] and rccl["grads"] == plain["grads"] and rccl["params"] == plain["params"], (plain, rccl)
+    differing = [n for n in plain["per"] if plain["per"][n] != rccl["per"][n]]
+    assert rccl["misses"] == 0 and not differing, (rccl["misses"], differing[:12])
+    assert rccl["loss"] == plain["loss"] and rccl["grads"] == plain["grads"] and rccl["params"] == plain["params"]
     assert abs(rccl["te_grad"] - plain["te_grad"]) <= 1e-6 * plain["te_grad"] and abs(rccl["te_param"] - plain["te_param"]) <= 1e-7 * plain["te_param"]
     wire = _run(USE_DP=1, CCLIP_DP_FORCE_COLLECTIVES=1, PORT=port + 1, WIRE16=1, CCLIP_TUNE_FILE=tune)   # bf16 gradient buckets on the wire
     assert wire["loss"] == plain["loss"]                                 # (step 2's loss still comes from fp32-reduced step 1? no:
