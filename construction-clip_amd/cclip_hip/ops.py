@@ -585,13 +585,56 @@ def text_embed(text_i32, emb, pos, x, *, rows: int, L: int) -> None:
                                c_int(emb.shape[0]), _p(x), _stream()), "cclip_text_embed")
 
 
+SCATTER_DETERMINISTIC = True     # False: the one-launch fp32-atomics kernel (sums rows of one token id in hardware order)
+_SEG_CHUNK = 64
+
+
 def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None, seq_stride: Optional[int] = None,
-                      seq_off: int = 0) -> None:
+                      seq_off: int = 0, keep: Optional[torch.Tensor] = None) -> None:
+    """demb[text[r]] += dx[(r // L) * seq_stride + seq_off + r % L] for r < rows (the embedding-table gradient).
+    keep: optional bool [rows] - rows known to carry a zero gradient (text positions after EOT) can be dropped up front.
+
+    Deterministic by default: the row list is sorted by token id (stable) and every run of equal ids is summed in list order
+    by the wave that owns its embedding row, runs longer than 64 rows through ordered partials (csrc/embed.hip).  The sort /
+    run bookkeeping below is integer index math on a [rows] vector; every float is added by the HIP kernels."""
     L = rows if L is None else L
     seq_stride = L if seq_stride is None else seq_stride
-    check(lib.cclip_embed_scatter_add(_p(text_i32), _p(dx), c_long(dx.stride(-2)), c_int(rows), c_int(demb.shape[1]),
-                                      c_int(demb.shape[0]), _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off),
-                                      _stream()), "cclip_embed_scatter_add")
+    if not SCATTER_DETERMINISTIC:
+        check(lib.cclip_embed_scatter_add(_p(text_i32), _p(dx), c_long(dx.stride(-2)), c_int(rows), c_int(demb.shape[1]),
+                                          c_int(demb.shape[0]), _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off),
+                                          _stream()), "cclip_embed_scatter_add")
+        return
+    dev = text_i32.device
+    V, D = demb.shape
+    tok = text_i32[:rows].clamp(0, V - 1)
+    if keep is not None:                                  # dropped rows sort to the end under a sentinel id and form no chunk
+        tok = torch.where(keep[:rows], tok, torch.full_like(tok, V))
+    n = rows
+    st, perm = torch.sort(tok, stable=True)
+    order = perm.to(torch.int32)
+    pos = torch.arange(n, device=dev, dtype=torch.int32)
+    valid = st < V
+    new_run = torch.ones(n, device=dev, dtype=torch.bool)
+    new_run[1:] = st[1:] != st[:-1]
+    nbig = torch.full((1,), n, device=dev, dtype=torch.int32)
+
+    def next_marked_after(mark):                          # for every p: the first q > p with mark[q], or n
+        at = torch.where(mark, pos, nbig.expand(n))
+        ge = torch.flip(torch.cummin(torch.flip(at, (0,)), 0).values, (0,))       # first q >= p
+        return torch.cat((ge[1:], nbig))
+
+    run_start_of = torch.cummax(torch.where(new_run, pos, torch.zeros_like(pos)), 0).values     # start of p's run
+    new_chunk = (new_run | (((pos - run_start_of) % _SEG_CHUNK) == 0)) & valid
+    cend = torch.where(new_chunk, next_marked_after(new_chunk | ~valid), torch.zeros_like(pos))
+    cidx = torch.cumsum(new_chunk.to(torch.int32), 0).to(torch.int32) - 1
+    nxt_run = next_marked_after(new_run)
+    total = cidx[-1:] + 1
+    cidx_at_next = torch.where(nxt_run < n, cidx[nxt_run.clamp(max=n - 1).long()] + (~new_chunk[nxt_run.clamp(max=n - 1).long()]).to(torch.int32), total.expand(n))
+    rlen = torch.where(new_run & valid, cidx_at_next - cidx, torch.zeros_like(pos)).to(torch.int32)
+    partial = torch.empty(n, D, device=dev, dtype=torch.float32)        # slot per chunk; only multi-chunk runs touch it
+    check(lib.cclip_embed_segsum(_p(order), _p(st.contiguous()), _p(cend.to(torch.int32).contiguous()), _p(cidx.contiguous()),
+                                 _p(rlen.contiguous()), c_int(n), _p(dx), c_long(dx.stride(-2)), c_int(D), _p(demb), c_int(L),
+                                 c_int(seq_stride), c_int(seq_off), _p(partial), _stream()), "cclip_embed_segsum")
 
 
 def caption_embed(prefix_proj, ids_i32, wte, wpe, x, *, B: int, P: int, Lt: int) -> None:

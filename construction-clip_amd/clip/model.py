@@ -402,7 +402,9 @@ class CLIP(nn.Module):
                    accumulate=A("positional_embedding"))
         if not A("token_embedding.weight"):
             g["token_embedding.weight"].zero_()
-        ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M)
+        # positions after a row's EOT carry an exactly-zero gradient (causal tower, EOT pooling): drop them from the row list
+        keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (c["rows"] - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
+        ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, keep=keep)
         ar.scale_grads(self._rt["txt_names"], 1.0 / S)
         ar.publish_grads(self._rt["txt_names"])
 

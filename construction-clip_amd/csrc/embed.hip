@@ -164,6 +164,75 @@ __global__ __launch_bounds__(256) void embed_scatter_add_kernel(const int* __res
   }
 }
 
+// ---- deterministic embedding gradient: segment-owned sums over rows SORTED by token id ----
+// The host sorts the row list by token id (stable: rows of one id keep their order) and marks, per list position p (integer
+// index math of fixed size - no host synchronisation, cclip_hip/ops.py):
+//   cend[p]  > 0: p starts a CHUNK (a piece of at most 64 rows of one id) that ends at cend[p];   0: not a chunk start
+//   cidx[p]     : index of the chunk p belongs to (= its partial slot)
+//   rlen[p]  > 0: p starts a RUN of equal ids made of rlen[p] chunks;                               0: not a run start
+// Pass 1: one wave per chunk start sums its rows in list order; a run that is a single chunk is added straight into its
+// embedding row (the wave owns it), the chunks of longer runs write partials.  Pass 2: one wave per multi-chunk run adds
+// its partials in chunk order.  No atomics: the result is bit-identical from run to run.
+__device__ __forceinline__ long seg_src_row(int r, int L, int seq_stride, int seq_off) {
+  return (long)(r / L) * seq_stride + seq_off + (r % L);
+}
+__global__ __launch_bounds__(256) void embed_segsum_kernel(const int* __restrict__ order, const int* __restrict__ tok_sorted,
+                                                           const int* __restrict__ cend, const int* __restrict__ cidx,
+                                                           const int* __restrict__ rlen, int n, const float* __restrict__ dx,
+                                                           long lddx, int D, float* __restrict__ demb, int L, int seq_stride,
+                                                           int seq_off, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p0 = blockIdx.x * 4 + wave; p0 < n; p0 += gridDim.x * 4) {
+    const int p1 = cend[p0];
+    if (p1 == 0) continue;                                              // not a chunk start (wave-uniform)
+    const bool direct = rlen[p0] == 1;
+    const int tok = tok_sorted[p0], slot = cidx[p0];
+    for (int col = lane * 4; col < D; col += 256) {                     // 4 floats per lane per pass
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      int p = p0;
+      for (; p + 4 <= p1; p += 4) {                                     // four independent row loads in flight, added in order
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(dx + seg_src_row(order[p + u], L, seq_stride, seq_off) * lddx + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; p < p1; ++p) {
+        const float4 v = *(const float4*)(dx + seg_src_row(order[p], L, seq_stride, seq_off) * lddx + col);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (direct) {
+        float4* o = (float4*)(demb + (long)tok * D + col);
+        float4 t = *o;
+        t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+        *o = t;
+      } else {
+        *(float4*)(partial + (long)slot * D + col) = s;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void embed_segsum_finish_kernel(const int* __restrict__ tok_sorted, const int* __restrict__ cidx,
+                                                                  const int* __restrict__ rlen, int n,
+                                                                  const float* __restrict__ partial, int D,
+                                                                  float* __restrict__ demb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p0 = blockIdx.x * 4 + wave; p0 < n; p0 += gridDim.x * 4) {
+    const int k = rlen[p0];
+    if (k <= 1) continue;                                               // not the start of a multi-chunk run
+    const int tok = tok_sorted[p0], s0 = cidx[p0];
+    for (int col = lane * 4; col < D; col += 256) {
+      float4* o = (float4*)(demb + (long)tok * D + col);
+      float4 t = *o;
+      for (int i = 0; i < k; ++i) {
+        const float4 v = *(const float4*)(partial + (long)(s0 + i) * D + col);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      *o = t;
+    }
+  }
+}
+
 // GPT-2 input rows for the prefix-caption model (CLIP_prefix_caption/train.py:258-263):
 //   x[b, s] = (s < P ? prefix_proj[b, s] : wte[ids[b, s - P]]) + wpe[s]
 __global__ __launch_bounds__(256) void caption_embed_kernel(const float* __restrict__ prefix_proj, const int* __restrict__ ids,
@@ -316,6 +385,19 @@ extern "C" int cclip_embed_scatter_add(const int32_t* text, const float* dx, int
   if (!text || !dx || !demb || rows <= 0 || D <= 0 || V <= 0 || L <= 0) return CCLIP_ERR_ARG;
   hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(grid_rows4(rows)), dim3(256), 0, stream, text, dx, (long)lddx, rows, D, V,
                      demb, L, seq_stride, seq_off);
+  return cclip_launch_status();
+}
+#endif
+
+#ifndef CCLIP_F16
+extern "C" int cclip_embed_segsum(const int32_t* order, const int32_t* tok_sorted, const int32_t* cend, const int32_t* cidx,
+                                  const int32_t* rlen, int32_t n, const float* dx, int64_t lddx, int32_t D, float* demb,
+                                  int32_t L, int32_t seq_stride, int32_t seq_off, float* partial, hipStream_t stream) {
+  if (!order || !tok_sorted || !cend || !cidx || !rlen || !dx || !demb || !partial) return CCLIP_ERR_ARG;
+  if (n <= 0 || D <= 0 || (D & 3) || (lddx & 3) || L <= 0) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(embed_segsum_kernel, dim3(grid_rows4(n)), dim3(256), 0, stream, order, tok_sorted, cend, cidx, rlen, n, dx,
+                     (long)lddx, D, demb, L, seq_stride, seq_off, partial);
+  hipLaunchKernelGGL(embed_segsum_finish_kernel, dim3(grid_rows4(n)), dim3(256), 0, stream, tok_sorted, cidx, rlen, n, partial, D, demb);
   return cclip_launch_status();
 }
 #endif

@@ -146,27 +146,30 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
     asm volatile("s_barrier" ::: "memory");
     const char* At = smem + cur * STAGE_BYTES_;
     const char* Bt = At + A_BYTES;
-    bf16x8 xf[2][MT], wf[2][4];
+    // fragments: A is refreshed IN PLACE one k-step ahead (xf[mt] of k-step 1 is read right after the four MFMAs that
+    // consumed xf[mt] of k-step 0), B is double-buffered: 24 + 32 registers instead of 80 - the parked tile's 48 fit
+    // without a spill (a spill reload inside this loop would wait on vmcnt, i.e. on the operand DMA in flight)
+    bf16x8 xf[MT], wf[2][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xf[0][mt] = frag_rows(At, wm0 + 16 * mt, 0, lane);
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = frag_rows(At, wm0 + 16 * mt, 0, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) wf[0][nt] = frag_rows(Bt, wn0 + 16 * nt, 0, lane);
     if (issuer) issue_group();       // inline asm, fixed in place: k-step 0's reads are in flight while the DMA issues
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xf[1][mt] = frag_rows(At, wm0 + 16 * mt, 1, lane);
-#pragma unroll
     for (int nt = 0; nt < 4; ++nt) wf[1][nt] = frag_rows(Bt, wn0 + 16 * nt, 1, lane);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[0][nt], xf[0][mt], acc[mt][nt]);
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[0][nt], xf[mt], acc[mt][nt]);
+      xf[mt] = frag_rows(At, wm0 + 16 * mt, 1, lane);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);            // k-step 1's B fragments first
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {                                // k-step 0's MFMAs carry k-step 1's fragment reads
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    for (int i = 0; i < MT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (TURN >= 0 && !issuer) {                                   // the streamed chunks of this group's store turn
       write_chunk(std::integral_constant<int, (TURN >= 0 ? CPS * TURN : 0)>{});
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream6_kernel(const GemmArgs p, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[1][nt], xf[1][mt], acc[mt][nt]);
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[1][nt], xf[mt], acc[mt][nt]);
     __builtin_amdgcn_sched_barrier(0);
     cursor_advance();
     cur ^= 1;

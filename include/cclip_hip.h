@@ -172,7 +172,8 @@ int cclip_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int
  * cclip_vit_embed_ln: x0 = patch_out + positional_embedding[t] (+ class_embedding at t = 0),
  *   x = ln_pre(x0); optional saves x0, mean, rstd.  All fp32 [rows = B*T, D].
  * cclip_text_embed: x[r] = token_embedding[text[r]] + positional_embedding[r % L] (pos may be NULL).
- * cclip_embed_scatter_add: ids are [n, L]; demb[text[r]] += dx[(r/L)*seq_stride + seq_off + r%L]  (fp32 atomics;
+ * cclip_embed_scatter_add: ids are [n, L]; demb[text[r]] += dx[(r/L)*seq_stride + seq_off + r%L]  (fp32 atomics - hardware
+ *   order, kept as the one-launch alternative; the default host path uses cclip_embed_segsum below;
  *   text tower: L = seq_stride = 77, seq_off = 0; caption model: the token part of a longer sequence).
  * cclip_caption_embed: x[b,s] = (s < P ? prefix_proj[b,s] : wte[ids[b,s-P]]) + wpe[s] - the
  *   `cat(clip_project(prefix), wte(cat(attribute,tokens)))` + GPT-2 position add of
@@ -189,6 +190,14 @@ int cclip_text_embed(const int32_t* text, const float* emb, const float* pos, in
 int cclip_embed_scatter_add(const int32_t* text, const float* dx, int64_t lddx, int32_t rows, int32_t D,
                             int32_t V, float* demb, int32_t L, int32_t seq_stride, int32_t seq_off,
                             hipStream_t stream);
+/* Deterministic form of the same sum (no atomics).  `order` lists the n rows sorted by token id (stable), tok_sorted their ids;
+ * per list position p: cend[p] > 0 marks the start of a CHUNK (at most 64 rows of one id) ending at cend[p], cidx[p] is the
+ * chunk index (= its slot in `partial`, [n, D] floats), rlen[p] > 0 marks the start of a run of equal ids made of rlen[p] chunks.
+ * One-chunk runs are added into demb[id] by the wave that owns them, longer runs through ordered partials (two launches).
+ * All tables are fixed-size index vectors: the caller needs no host synchronisation.  Bit-identical from run to run. */
+int cclip_embed_segsum(const int32_t* order, const int32_t* tok_sorted, const int32_t* cend, const int32_t* cidx,
+                       const int32_t* rlen, int32_t n, const float* dx, int64_t lddx, int32_t D, float* demb, int32_t L,
+                       int32_t seq_stride, int32_t seq_off, float* partial, hipStream_t stream);
 int cclip_caption_embed(const float* prefix_proj, const int32_t* ids, const float* wte, const float* wpe,
                         int32_t B, int32_t P, int32_t Lt, int32_t D, int32_t V, float* x, hipStream_t stream);
 int cclip_add_positional(const float* emb, const float* wpe, int32_t rows, int32_t S, int32_t D, float* x,

@@ -244,6 +244,45 @@ def test_patchify_and_embeds():
     close("scatter", demb, ref, 1e-5, 1e-5)
 
 
+def test_embedding_gradient_is_deterministic_and_handles_long_runs():
+    """csrc/embed.hip embed_segsum: the embedding-table gradient summed WITHOUT atomics - rows sorted by token id, one owner
+    per id, runs longer than 64 rows through ordered partials.  A hot id (thousands of rows: the SOT / EOT tokens of a batch),
+    dropped rows (`keep`), the GPT-2 row mapping (seq_stride / seq_off), accumulation into a non-zero table; two launches agree
+    bit for bit, and with the atomics kernel to rounding."""
+    o = ops()
+    g = G(11)
+    V, W, B, L = 500, 512, 64, 77
+    text = torch.randint(1, V, (B * L,), device="cuda", generator=g, dtype=torch.int32)
+    text.view(B, L)[:, 0] = V - 2                                       # every sequence starts with the same id: runs of B rows
+    text.view(B, L)[:, 5::7] = 3                                        # a hot id with hundreds of rows
+    dx = torch.randn(B * L, W, device="cuda", generator=g)
+    base = torch.randn(V, W, device="cuda", generator=g)
+    keep = torch.rand(B * L, device="cuda", generator=g) > 0.25
+    outs = []
+    for _ in range(2):
+        demb = base.clone()
+        o.embed_scatter_add(text, dx, demb, rows=B * L, keep=keep)
+        outs.append(demb)
+    assert torch.equal(outs[0], outs[1])
+    ref = base.double().index_add_(0, text[keep].long(), dx[keep].double())
+    close("segsum", outs[0], ref.float(), 1e-5, 1e-4)
+    o.SCATTER_DETERMINISTIC = False
+    try:
+        d2 = base.clone()
+        o.embed_scatter_add(text, dx * keep[:, None], d2, rows=B * L)
+    finally:
+        o.SCATTER_DETERMINISTIC = True
+    close("segsum vs atomics", outs[0], d2, 1e-5, 1e-4)
+    # GPT-2 mapping: ids [n_seq, Lt] sit at rows b*S + P + j of the gradient
+    S, P, Lt = 30, 6, 20
+    ids = torch.randint(0, V, (B * Lt,), device="cuda", generator=g, dtype=torch.int32)
+    dxs = torch.randn(B * S, W, device="cuda", generator=g)
+    d3 = torch.zeros(V, W, device="cuda")
+    o.embed_scatter_add(ids, dxs, d3, rows=B * Lt, L=Lt, seq_stride=S, seq_off=P)
+    ref3 = torch.zeros(V, W, device="cuda", dtype=torch.float64).index_add_(0, ids.long(), dxs.view(B, S, W)[:, P:P + Lt].reshape(-1, W).double())
+    close("segsum gpt2 rows", d3, ref3.float(), 1e-5, 1e-4)
+
+
 @pytest.mark.parametrize("R,C,bf", [(1000, 768, True), (50, 2304, False), (4097, 104, True), (300, 100, False)])
 def test_colsum(R, C, bf):
     o = ops()
