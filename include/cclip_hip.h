@@ -85,7 +85,7 @@ typedef struct cclip_gemm_desc {
                         *     quantisation option - 9.39 rounds of 0.75-size tiles instead of 7.03 rounds of full ones.
                         * 6 = persistent 192x256 (configuration 5's K loop) whose finished tile is parked as packed 16-bit values
                         *     and streamed out under the next tile's K loop - forward layout, N % 256 == 0, N <= 4096,
-                        *     K % 64 == 0, K >= 384, epilogue {16-bit out | pre-activation + QuickGELU}; status 1 otherwise.
+                        *     K % 128 == 0, K >= 384, M >= 192, epilogue = one 16-bit output (alpha, bias); status 1 otherwise.
                         * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
   /* wgrad layout (0,0) only: colsum_out[m] (+)= sum_k A(m,k) - the BIAS gradient of the layer whose weight gradient this
    * call computes (A = dY^T), taken off the operand tiles already in LDS by one extra MFMA per m-tile against an all-ones
