@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const GemmArgs p, i
     if (EPI == 1) {
       bf16x8 t;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { t[r] = (bf16)v[r]; v[r] = (float)t[r]; }    // activation on the pre-activation AS STORED
+      for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
       *(bf16x8*)(p.out_pre + (long)m * p.ldc + n0) = t;
     }
     if (ACT != CCLIP_ACT_NONE) {

@@ -12,8 +12,9 @@
 //
 // Epilogue forms (forward operand layout only; with the transposed weight shadows that covers the dgrad GEMMs too):
 //   EPI 0: out16 = alpha*acc + bias                                  (qkv projection, dgrad outputs)
-//   EPI 1: pre16 = alpha*acc + bias;  out16 = ACT(pre16 as stored)   (training fc: the activation is evaluated on the
-//          ROUNDED pre-activation in every tile configuration, so all of them produce the same bits)
+//   EPI 1: pre16 = alpha*acc + bias;  out16 = ACT(pre16 as stored)   (compiled, NOT offered: the parked tile is 16-bit, so
+//          the activation would see the rounded pre-activation - different bits from every other configuration, and a
+//          training forward that differs from the inference forward; it also measured 43 % slower than configuration 3)
 // vmcnt: a wave has ONE in-order counter for its LDS-DMA and its stores, so "my DMA has landed" also means "every older store
 // of mine has been acknowledged".  Measured (round 2, PMC): with every wave issuing both each iteration a store had less
 // than one iteration to retire and the DMA waits grew by ~900 clocks per iteration (267 vs 225 us on the qkv projection).

@@ -438,18 +438,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bsv[h][r];
         if (p.out_pre) {
-          // the pre-activation is an OUTPUT (saved for backward): the activation is then evaluated on it AS STORED (rounded
-          // to 16 bits) - what backward differentiates, and the one rule every tile configuration can follow bit for bit
-          // (the streaming configurations park the finished tile in 16 bits before the activation is applied)
           bf16* o = p.out_pre + (long)m * p.ldc + n0;
-          bf16x8 t;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) { t[r] = (bf16)v[r]; v[r] = (float)t[r]; }
           if (full) {
+            bf16x8 t;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
             *(bf16x8*)o = t;
           } else {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = t[r];
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
           }
         }
         if (ACT != CCLIP_ACT_NONE) {

@@ -128,3 +128,31 @@ def test_native_decode_driver_equals_python_launch_sequence(monkeypatch):
         assert (a - b).abs().max() < 5e-3, (a - b).abs().max()
     for i in (1, 2):
         assert (outs["python"][i].float() - outs["native"][i].float()).abs().max() < 2e-2
+
+
+def test_generate_beam_and_generate2_at_gpt2_small_geometry():
+    """The decode path at BASELINE configs[3]'s real geometry (GPT-2-small, V = 21128, 12 layers, prefix 20 + attribute 20):
+    the KV-cached `generate_beam` (beam 3, temperature 0.5) and `generate2` (top-p 0.8) must produce the oracle's tokens,
+    lengths and scores - the oracle re-runs the full forward on the growing sequence at every step, as the reference does
+    (test.py:381, :489)."""
+    from clip_caption import ClipCaptionModel, GPT2_MODELS, generate2, generate_beam, init_caption_state_dict, synthetic_caption_batch
+    from oracle import caption_oracle as CO
+    geo = GPT2_MODELS["ckiplab/gpt2-base-chinese"]
+    sd = init_caption_state_dict(geo, 77)
+    model = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+    model.load_state_dict(sd)
+    model = model.cuda().eval().half()
+    _, _, prefix, attribute = synthetic_caption_batch(1, geo, 6, 78)
+    emb = _prefix_embed(model, geo, prefix, attribute)
+    ref_emb = torch.cat((CO.mlp_mapper(sd, prefix).view(1, geo.prefix_length, geo.n_embd), sd["model.transformer.wte.weight"][attribute]), dim=1)
+    assert (emb.cpu() - ref_emb).abs().max() < 2e-3
+    steps = 10
+    texts, tokens, lengths, scores = generate_beam(model, _Tok(), beam_size=3, embed=emb, entry_length=steps, stop_token=102, return_tokens=True)
+    rt, rl, rs, trace = CO.generate_beam_tokens(sd, ref_emb, geo.n_head, beam_size=3, entry_length=steps, stop_token=102)
+    assert torch.equal(lengths.cpu(), rl)
+    assert (scores.cpu() - rs).abs().max() < 2e-2
+    order, rorder = scores.argsort(descending=True), rs.argsort(descending=True)
+    assert torch.equal(tokens[order[0]].cpu(), rt[rorder[0]]), (tokens.cpu(), rt)
+    rt2, _ = CO.generate2_tokens(sd, ref_emb, geo.n_head, entry_length=steps, stop_token=102)
+    _, tok2 = generate2(model, _Tok(), embed=emb, entry_length=steps, stop_token=102, return_tokens=True)
+    assert torch.equal(tok2.cpu(), rt2), (tok2.cpu(), rt2)

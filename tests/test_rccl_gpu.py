@@ -37,7 +37,7 @@ red = parallel.GradReducer(model, max_bucket_elems=8 << 20, wire_dtype=torch.bfl
 B = 128
 img = torch.randn(B, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
 txt = synthetic_text(B, geo, 2).cuda()
-early = []
+early, losses = [], []
 for _ in range(2):
     opt.zero_grad()
     fi, ft = model.encode_image_text(img, txt)
@@ -46,6 +46,7 @@ for _ in range(2):
     loss.backward()
     pend = red.finish()
     early.append(red.fired_early)
+    losses.append(loss.item().hex())
     opt.step(pending=pend)
 torch.cuda.synchronize()
 ar = model.arena
@@ -60,7 +61,7 @@ def digest(flat):
 
 (gh, gte), (ph, pte) = digest(ar.gflat), digest(ar.flat)
 per = {n: hashlib.sha256(ar.g[n].cpu().numpy().tobytes()).hexdigest()[:12] for n in ar.names if n != "token_embedding.weight"}
-out = dict(loss=loss.item().hex(), params=ph, grads=gh, te_grad=gte, te_param=pte, early=early, buckets=len(red.buckets),
+out = dict(loss=loss.item().hex(), losses=losses, params=ph, grads=gh, te_grad=gte, te_param=pte, early=early, buckets=len(red.buckets),
            logit_scale=model.logit_scale.item(), per=per, misses=__import__("cclip_hip").ops._TUNE_STATE["misses"])
 if use_dp:
     dist.destroy_process_group()
@@ -85,7 +86,8 @@ def test_one_rank_rccl_step_equals_plain_step(tmp_path):
     assert plain["early"] == [0, 0]
     differing = [n for n in plain["per"] if plain["per"][n] != rccl["per"][n]]
     assert rccl["misses"] == 0 and not differing, (rccl["misses"], differing[:12])
-    assert rccl["loss"] == plain["loss"] and rccl["grads"] == plain["grads"] and rccl["params"] == plain["params"]
+    summary = {k: (plain[k], rccl[k]) for k in ("losses", "logit_scale", "te_grad", "te_param", "params", "grads")}
+    assert rccl["losses"] == plain["losses"] and rccl["grads"] == plain["grads"] and rccl["params"] == plain["params"], summary
     assert abs(rccl["te_grad"] - plain["te_grad"]) <= 1e-6 * plain["te_grad"] and abs(rccl["te_param"] - plain["te_param"]) <= 1e-7 * plain["te_param"]
     wire = _run(USE_DP=1, CCLIP_DP_FORCE_COLLECTIVES=1, PORT=port + 1, WIRE16=1, CCLIP_TUNE_FILE=tune)   # bf16 gradient buckets on the wire
     assert wire["loss"] == plain["loss"]                                 # (step 2's loss still comes from fp32-reduced step 1? no:
