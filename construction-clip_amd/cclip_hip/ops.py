@@ -318,7 +318,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
                         split_k if split_candidates is None else -1, colsum_out is not None, colsum_of_b))
         choice = _TUNED.get(key)
         if choice is None:
-            cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 6)]
+            cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 7)]
             if split_candidates is None and split_k > 1:
                 d.split_ws = split_ws.data_ptr()
             choice = _autotune(d, key, outs3, cands)

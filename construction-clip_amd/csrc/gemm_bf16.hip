@@ -36,7 +36,7 @@ bool cclip_gemm_launch_cfg2(int lay, int act, dim3 grid, hipStream_t stream, con
 bool cclip_gemm_launch_cfg3(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg4(int lay, int act, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg5(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
-bool cclip_gemm_launch_cfg6(int lay, int act, hipStream_t stream, const GemmArgs& a);
+bool cclip_gemm_launch_cfg7(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmArgs& a);
 
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
@@ -140,17 +140,14 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     if (splits > 1 || !cclip_gemm_launch_cfg4(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
     return cclip_launch_status();
   }
-  if (cfg == 6) {     // persistent 192x256 with the finished tile parked in 16 bits and streamed under the next K loop - refused otherwise
-    if (splits > 1 || !cclip_gemm_launch_cfg6(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
-    return cclip_launch_status();
-  }
-  if (cfg <= 0 || cfg > 5) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);
-  if (cfg < 1 || cfg > 5) cfg = 1;
-  const int bm = cfg == 1 ? 128 : cfg == 5 ? 192 : 256, bn = (cfg == 3 || cfg == 5) ? 256 : 128;
+  if (cfg <= 0 || cfg > 7 || cfg == 6) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);
+  if (cfg < 1 || cfg > 7 || cfg == 6) cfg = 1;
+  const int bm = cfg == 1 ? 128 : cfg == 5 ? 192 : 256, bn = (cfg == 3 || cfg == 5 || cfg == 7) ? 256 : 128;
   const int tiles = ((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn);
   dim3 grid(tiles, splits);
   const int lay = d->a_kcontig * 2 + d->b_kcontig;   // 3 = fwd, 2 = dgrad/Conv1D, 0 = wgrad
-  const bool launched = cfg == 5   ? cclip_gemm_launch_cfg5(lay, d->act, grid, stream, a)
+  const bool launched = cfg == 7   ? cclip_gemm_launch_cfg7(lay, d->act, grid, stream, a)
+                        : cfg == 5 ? cclip_gemm_launch_cfg5(lay, d->act, grid, stream, a)
                         : cfg == 3 ? cclip_gemm_launch_cfg3(lay, d->act, grid, stream, a)
                         : cfg == 2 ? cclip_gemm_launch_cfg2(lay, d->act, grid, stream, a)
                                    : cclip_gemm_launch_cfg1(lay, d->act, grid, stream, a);

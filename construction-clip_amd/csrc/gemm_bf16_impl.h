@@ -196,7 +196,10 @@ __device__ __forceinline__ void epi_loads(const GemmArgs& p, int row_base, int c
 // WM x WN waves, each a (16*MT)x64 output sub-tile: block tile = (16*MT*WM) x (64*WN).  STAGES LDS stages; the DMA
 // for tile kt+STAGES-1 is issued while tile kt is multiplied, with a COUNTED s_waitcnt vmcnt so that the
 // younger stages stay in flight across the barrier (a plain __syncthreads would drain them).
-template <int A_KC, int B_KC, int ACT, int WM, int WN, int STAGES, int MT>
+// ROT = 1: ROTATED K loop (k_iter_rot below): the barrier of K-tile kt is followed by k-step 1 of tile kt-1 - whose
+// fragments are already in registers - while the fragments of tile kt stream in, so the post-barrier fragment-read burst
+// (8 waves x 12 ds_read_b128 before the first MFMA can issue) is no longer exposed time.
+template <int A_KC, int B_KC, int ACT, int WM, int WN, int STAGES, int MT, int ROT = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, BM_ = 16 * MT * WM, BN_ = 64 * WN;
   constexpr int NSA = (BM_ + 127) / 128, NSB = (BN_ + 127) / 128;   // 128-wide sub-tiles per operand
@@ -365,6 +368,77 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM, 0);
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   };
+  // ---- rotated iteration (ROT): loop-carried fragments of k-step 1.  Iteration kt: barrier; k-step 1 of tile kt-1 while
+  // k-step 0 of tile kt is read; the DMA group of tile kt+PD; k-step 0 of tile kt while its k-step 1 is read.  Every LDS
+  // read of stage(kt) still sits between barrier kt and barrier kt+1, so the stage hand-over is that of the plain loop.
+  bf16x8 lxf[2][ROT ? MT : 1], lwf[2][4];
+  auto k_iter_rot = [&](int kt, auto dma_tag, auto first_tag, int wait_tiles) {
+    constexpr bool DMA = decltype(dma_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int LMT = ROT ? MT : 1;
+    if (PD >= 3 && wait_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+    else if (PD >= 2 && wait_tiles >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const char* At = smem + cur * STAGE_BYTES_ + a_off;
+    const char* Bt = smem + cur * STAGE_BYTES_ + NSA * TILE_BYTES + b_off;
+#pragma unroll
+    for (int mt = 0; mt < LMT; ++mt)
+      lxf[0][mt] = A_KC ? frag_rows(At, a_row + 16 * mt, 0, lane) : frag_cols<0>(At, a_row, mt, 0, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      lwf[0][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 0, lane) : frag_cols<1>(Bt, b_row, nt, 0, lane);
+    if (!FIRST) {
+#pragma unroll
+      for (int mt = 0; mt < LMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(lwf[1][nt], lxf[1][mt], acc[mt][nt]);
+    }
+    if (DMA) {
+      int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
+      char* sb = smem + ns * STAGE_BYTES_;
+      stage_tile<A_KC, 0, NSA, NW, AI>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
+      stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave, lane);
+    }
+    constexpr int RD = (A_KC ? LMT : 2 * LMT) + (B_KC ? 4 : 8);
+    constexpr int NM = 4 * LMT;
+    if (!FIRST) {      // k-step 1 of the previous tile carries this tile's k-step 0 reads, then the DMA group
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {      // MFMA first: the wait for the loop-carried fragments then precedes every new read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (DMA) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, (NM - RD) / G > 0 ? (NM - RD) / G : 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+      if (DMA) __builtin_amdgcn_sched_group_barrier(0x010, G, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < LMT; ++mt)
+      lxf[1][mt] = A_KC ? frag_rows(At, a_row + 16 * mt, 1, lane) : frag_cols<0>(At, a_row, mt, 1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      lwf[1][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 1, lane) : frag_cols<1>(Bt, b_row, nt, 1, lane);
+#pragma unroll
+    for (int mt = 0; mt < LMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(lwf[0][nt], lxf[0][mt], acc[mt][nt]);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM / RD > 0 ? NM / RD : 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
+  };
   int kt = kt0;
   int cs = 0;
   if constexpr (WG_LAYOUT) {
@@ -379,8 +453,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     }
   }
   if (cs == 0) {
-    for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::integral_constant<int, 0>{}, PD - 1);
-    for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::integral_constant<int, 0>{}, kt1 - 1 - kt);
+    if constexpr (ROT != 0) {
+      if (kt < kt1) {
+        if (kt + PD < kt1) k_iter_rot(kt, std::true_type{}, std::true_type{}, PD - 1);
+        else k_iter_rot(kt, std::false_type{}, std::true_type{}, kt1 - 1 - kt);
+        ++kt;
+        for (; kt + PD < kt1; ++kt) k_iter_rot(kt, std::true_type{}, std::false_type{}, PD - 1);
+        for (; kt < kt1; ++kt) k_iter_rot(kt, std::false_type{}, std::false_type{}, kt1 - 1 - kt);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)          // k-step 1 of the last tile
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(lwf[1][nt], lxf[1][mt], acc[mt][nt]);
+      }
+    } else {
+      for (; kt + PD < kt1; ++kt) k_iter(kt, std::true_type{}, std::integral_constant<int, 0>{}, PD - 1);
+      for (; kt < kt1; ++kt) k_iter(kt, std::false_type{}, std::integral_constant<int, 0>{}, kt1 - 1 - kt);
+    }
   }
   if constexpr (WG_LAYOUT) {
     if (cs == 1 && wn == 0 && (lane >> 4) == 0) {         // D[any row][col li] = sum_k A(16 mt + li, k): take row 0
@@ -483,11 +571,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 }
 
 // launcher for one tile configuration; instantiates exactly the (layout, activation) pairs the hot path issues
-template <int WM, int WN, int STAGES, int MT>
+template <int WM, int WN, int STAGES, int MT, int ROT = 0>
 static bool gemm_launch_cfg(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a) {
   dim3 block(64 * WM * WN);
   if (a.colsum_dst && MT > 6) return false;                 // fused bias gradient: not in the 128x64-per-wave configuration (registers)
-#define LAUNCH(AK, BKC, ACTV) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, ACTV, WM, WN, STAGES, MT>), grid, block, 0, stream, a)
+  if (ROT && lay != 3) return false;                         // the rotated loop is instantiated for the forward layout only
+#define LAUNCH(AK, BKC, ACTV) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, ACTV, WM, WN, STAGES, MT, ROT>), grid, block, 0, stream, a)
   if (lay == 3) {
     switch (act) {
       case CCLIP_ACT_NONE: LAUNCH(1, 1, CCLIP_ACT_NONE); return true;
@@ -499,17 +588,20 @@ static bool gemm_launch_cfg(int lay, int act, dim3 grid, hipStream_t stream, con
       case CCLIP_ACT_DRELU: LAUNCH(1, 1, CCLIP_ACT_DRELU); return true;
       default: return false;
     }
-  } else if (lay == 2) {
-    switch (act) {
-      case CCLIP_ACT_NONE: LAUNCH(1, 0, CCLIP_ACT_NONE); return true;
-      case CCLIP_ACT_GELU_NEW: LAUNCH(1, 0, CCLIP_ACT_GELU_NEW); return true;
-      case CCLIP_ACT_DQUICKGELU: LAUNCH(1, 0, CCLIP_ACT_DQUICKGELU); return true;
-      case CCLIP_ACT_DTANH: LAUNCH(1, 0, CCLIP_ACT_DTANH); return true;
-      case CCLIP_ACT_DRELU: LAUNCH(1, 0, CCLIP_ACT_DRELU); return true;
-      default: return false;
-    }
   }
-  if (act == CCLIP_ACT_NONE) { LAUNCH(0, 0, CCLIP_ACT_NONE); return true; }
+  if constexpr (ROT == 0) {      // (the rotated loop is instantiated for the forward layout only)
+    if (lay == 2) {
+      switch (act) {
+        case CCLIP_ACT_NONE: LAUNCH(1, 0, CCLIP_ACT_NONE); return true;
+        case CCLIP_ACT_GELU_NEW: LAUNCH(1, 0, CCLIP_ACT_GELU_NEW); return true;
+        case CCLIP_ACT_DQUICKGELU: LAUNCH(1, 0, CCLIP_ACT_DQUICKGELU); return true;
+        case CCLIP_ACT_DTANH: LAUNCH(1, 0, CCLIP_ACT_DTANH); return true;
+        case CCLIP_ACT_DRELU: LAUNCH(1, 0, CCLIP_ACT_DRELU); return true;
+        default: return false;
+      }
+    }
+    if (lay == 0 && act == CCLIP_ACT_NONE) { LAUNCH(0, 0, CCLIP_ACT_NONE); return true; }
+  }
   return false;
 #undef LAUNCH
 }

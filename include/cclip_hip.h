@@ -83,9 +83,8 @@ typedef struct cclip_gemm_desc {
                         *     epilogue forms {16-bit out | pre-activation + activation | fp32 out + residual}; status 1 otherwise.
                         * 5 = 192x256 (configuration 3's K loop with 96x64 per wave; K-contiguous A only): a tile-count
                         *     quantisation option - 9.39 rounds of 0.75-size tiles instead of 7.03 rounds of full ones.
-                        * 6 = persistent 192x256 (configuration 5's K loop) whose finished tile is parked as packed 16-bit values
-                        *     and streamed out under the next tile's K loop - forward layout, N % 256 == 0, N <= 4096,
-                        *     K % 128 == 0, K >= 384, M >= 192, epilogue = one 16-bit output (alpha, bias); status 1 otherwise.
+                        * 7 = configuration 3 with the ROTATED K loop (k-step 1 of the previous K-tile is multiplied right after the
+                        *     barrier while the new tile's fragments are read) - forward layout only; status 1 otherwise.
                         * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
   /* wgrad layout (0,0) only: colsum_out[m] (+)= sum_k A(m,k) - the BIAS gradient of the layer whose weight gradient this
    * call computes (A = dY^T), taken off the operand tiles already in LDS by one extra MFMA per m-tile against an all-ones

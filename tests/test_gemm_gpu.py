@@ -57,13 +57,15 @@ LAYOUTS = [(True, True), (True, False), (False, False)]
 SHAPES = [(128, 128, 64), (256, 384, 192), (450, 768, 768), (264, 200, 72), (1000, 2304, 768), (72, 136, 3072)]
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 5, 7])
 @pytest.mark.parametrize("akc,bkc", LAYOUTS)
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_gemm_plain(M, N, K, akc, bkc, cfg):
     ops = _ops()
     if not akc and M % 8:
         pytest.skip("a_kcontig=0 needs M % 8 == 0")
+    if cfg == 7 and not (akc and bkc):
+        pytest.skip("configuration 7 (rotated K loop) is built for the forward layout")
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
     A = torch.randn((M, K) if akc else (K, M), device="cuda", generator=g).bfloat16()
     B = torch.randn((N, K) if bkc else (K, N), device="cuda", generator=g).bfloat16()
@@ -78,9 +80,11 @@ def test_gemm_plain(M, N, K, akc, bkc, cfg):
 
 @pytest.mark.parametrize("act,akc,bkc", [(1, True, True), (2, True, True), (4, True, True), (18, True, True),
                                          (3, True, False), (16, True, False), (17, True, False), (19, True, False)])
-@pytest.mark.parametrize("cfg", [0, 2, 3, 5])
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 7])
 def test_gemm_epilogues(act, akc, bkc, cfg):
     ops = _ops()
+    if cfg == 7 and not (akc and bkc):
+        pytest.skip("configuration 7 (rotated K loop) is built for the forward layout")
     M, N, K = 300, 264, 256
     g = torch.Generator(device="cuda").manual_seed(act)
     A = (torch.randn(M, K, device="cuda", generator=g) * 0.1).bfloat16()
@@ -209,56 +213,6 @@ def test_gemm_streaming_config_refuses_what_it_does_not_cover():
     B = torch.zeros(128, 256, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(CclipError):
         o.gemm_bf16(A, B, out_bf16=torch.empty(256, 128, device="cuda", dtype=torch.bfloat16), tile_config=4)
-
-
-# ---- tile configuration 6: persistent 192x256, finished tile parked in 16 bits and streamed under the next K loop --------
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K,kind", [(192, 256, 768, "out16"), (500, 256, 384, "out16"), (51200, 768, 768, "out16"),
-                                         (12800, 2304, 512, "out16"), (9000, 512, 3072, "out16"), (78848 // 4, 1536, 512, "out16"),
-                                         (51200 // 2, 3072, 768, "out16"), (1000, 256, 1024, "out16")])
-def test_gemm_streaming192_config(M, N, K, kind, dt):
-    """One tile, a ragged last row tile (anchored at M - 192), many tiles per workgroup, both streaming rates (one / two
-    chunks per K iteration: K >= 768 / K < 768), K longer than the streaming window; against fp32 torch AND bit for bit against
-    configuration 3 (same MFMA order, same epilogue arithmetic: the tuner may pick either)."""
-    o = _ops()
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(dt)
-    B = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(dt)
-    bias = torch.randn(N, device="cuda", generator=g)
-    pre = A.float() @ B.float().t() * 0.75 + bias
-    outs = {}
-    for cfg in (6, 3):
-        out = torch.full((M, N), float("nan"), device="cuda").to(dt)
-        outp = torch.full((M, N), float("nan"), device="cuda").to(dt) if kind == "gelu2" else None
-        o.gemm_bf16(A, B, alpha=0.75, bias=bias, act=1 if kind == "gelu2" else 0, out_bf16=out, out_pre=outp, tile_config=cfg)
-        outs[cfg] = (out, outp)
-    torch.cuda.synchronize()
-    out, outp = outs[6]
-    if kind == "gelu2":
-        _report("streamed192 pre-activation", outp, pre, 1e-2)
-        _report("streamed192 activation", out, _ref_act(pre, 1, None), 1e-2)
-        assert torch.equal(outp, outs[3][1])
-    else:
-        _report("streamed192 16-bit out", out, pre, 1e-2)
-    assert torch.equal(out, outs[3][0])
-
-
-def test_gemm_streaming192_refuses_what_it_does_not_cover():
-    from cclip_hip._lib import CclipError
-    o = _ops()
-    bad = [((256, 768), (300, 768), {}),                        # N not a multiple of 256
-           ((256, 320), (256, 320), {}),                        # K too short for the streaming window
-           ((100, 768), (256, 768), {})]                        # fewer than 192 rows
-    for ashape, bshape, kw in bad:
-        A = torch.zeros(*ashape, device="cuda", dtype=torch.bfloat16)
-        B = torch.zeros(*bshape, device="cuda", dtype=torch.bfloat16)
-        with pytest.raises(CclipError):
-            o.gemm_bf16(A, B, out_bf16=torch.empty(ashape[0], bshape[0], device="cuda", dtype=torch.bfloat16), tile_config=6, **kw)
-    A = torch.zeros(256, 768, device="cuda", dtype=torch.bfloat16)
-    B = torch.zeros(256, 768, device="cuda", dtype=torch.bfloat16)
-    with pytest.raises(CclipError):                              # fp32 residual epilogue: not a form it streams
-        x = torch.zeros(256, 256, device="cuda")
-        o.gemm_bf16(A, B, residual=x, out_f32=x, tile_config=6)
 
 
 # ---- skinny path: M <= 8 rows against K-strided (Conv1D) weights = the projections of a KV-cached decode step -----------

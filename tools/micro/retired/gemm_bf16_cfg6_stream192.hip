@@ -1,3 +1,4 @@
+// RETIRED (round 2): never selected by the tuner - see DESIGN.md section 6.  Kept for reference, not built.
 // tile configuration 6 ("streaming 192x256"): PERSISTENT workgroups with the K loop of configuration 5 (8 waves of 96x64,
 // two 56 KiB LDS stages) whose finished tile is written out UNDER THE NEXT TILE'S K LOOP.
 //
