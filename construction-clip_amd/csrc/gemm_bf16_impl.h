@@ -496,9 +496,107 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     }
   }
   // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
-  // Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then the
-  // math and the stores - one memory round trip per batch instead of one per 8-column run.
   if (!PRE) epi_bias(p, bn0 + wn0, g, bsv);
+  // FAST PATHS.  The general epilogue below serves every combination of outputs, ragged M / N edges and unaligned tails; it
+  // compiles to ~5700 instructions in ~1000 basic blocks (exec-mask branches around every optional piece), of which a wave
+  // executes a couple of thousand per tile - with K = 512 / 768 that is a visible share of a tile's life (PMC, round 2:
+  // 3 VALU + 1 SALU instructions per MFMA over the whole kernel against 0.6 + 0.6 inside the K loop).  Interior tiles of the
+  // four forms the hot path issues take a branch-free straight-line version instead; same arithmetic, same rounding.
+  const bool interior = bm0 + BM_ <= p.M && bn0 + BN_ <= p.N && !(p.N & 7) && !p.split_ws;
+  if (interior) {
+    const long row0 = (long)(bm0 + wm0 + li) * p.ldc + (bn0 + wn0 + 8 * g);
+    if (ACT < CCLIP_ACT_DQUICKGELU && p.out_bf16 && !p.out_f32 && !p.residual && (ACT != CCLIP_ACT_NONE || !p.out_pre)) {
+      // 16-bit output (+ pre-activation when the activation's input is saved for backward): qkv, fc, every plain dgrad
+      bf16* ob = p.out_bf16 + row0;
+      bf16* op = p.out_pre ? p.out_pre + row0 : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[mt][2 * h][r] * p.alpha + bsv[h][r];
+            v[4 + r] = acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r];
+          }
+          const long o = (long)(16 * mt) * p.ldc + 32 * h;
+          if (ACT != CCLIP_ACT_NONE) {
+            if (op) {
+              bf16x8 t;
+#pragma unroll
+              for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+              *(bf16x8*)(op + o) = t;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], 0.f);
+          }
+          bf16x8 t;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+          *(bf16x8*)(ob + o) = t;
+        }
+      return;
+    }
+    if (ACT == CCLIP_ACT_NONE && !PRE && p.out_f32 && p.residual && !p.out_bf16 && !p.out_pre && p.ldr == p.ldc) {
+      // fp32 residual stream: out = alpha*acc + bias + residual (usually in place): out-proj, c_proj
+      const float* rp = p.residual + row0;
+      float* of = p.out_f32 + row0;
+#pragma unroll
+      for (int mb = 0; mb < MT; mb += 2) {
+        float4 rr[2][2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const long o = (long)(16 * (mb + mi)) * p.ldc + 32 * h;
+            rr[mi][h][0] = *(const float4*)(rp + o); rr[mi][h][1] = *(const float4*)(rp + o + 4);
+          }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int mt = mb + mi;
+            const long o = (long)(16 * mt) * p.ldc + 32 * h;
+            float4 a0, a1;
+            a0.x = acc[mt][2 * h][0] * p.alpha + bsv[h][0] + rr[mi][h][0].x; a0.y = acc[mt][2 * h][1] * p.alpha + bsv[h][1] + rr[mi][h][0].y;
+            a0.z = acc[mt][2 * h][2] * p.alpha + bsv[h][2] + rr[mi][h][0].z; a0.w = acc[mt][2 * h][3] * p.alpha + bsv[h][3] + rr[mi][h][0].w;
+            a1.x = acc[mt][2 * h + 1][0] * p.alpha + bsv[h][4] + rr[mi][h][1].x; a1.y = acc[mt][2 * h + 1][1] * p.alpha + bsv[h][5] + rr[mi][h][1].y;
+            a1.z = acc[mt][2 * h + 1][2] * p.alpha + bsv[h][6] + rr[mi][h][1].z; a1.w = acc[mt][2 * h + 1][3] * p.alpha + bsv[h][7] + rr[mi][h][1].w;
+            *(float4*)(of + o) = a0; *(float4*)(of + o + 4) = a1;
+          }
+      }
+      return;
+    }
+    if (HAS_AUX && !PRE && p.out_bf16 && !p.out_f32 && !p.out_pre && !p.residual && p.ldaux == p.ldc) {
+      // activation derivative: out16 = act'(aux) * (alpha*acc + bias): the dgrad of the MLP's second projection
+      const bf16* ap = p.aux + row0;
+      bf16* ob = p.out_bf16 + row0;
+#pragma unroll
+      for (int mb = 0; mb < MT; mb += 2) {
+        bf16x8 ax[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) ax[mi][h] = *(const bf16x8*)(ap + (long)(16 * (mb + mi)) * p.ldc + 32 * h);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int mt = mb + mi;
+            bf16x8 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              t[r] = (bf16)act_apply<ACT>(acc[mt][2 * h][r] * p.alpha + bsv[h][r], (float)ax[mi][h][r]);
+              t[4 + r] = (bf16)act_apply<ACT>(acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r], (float)ax[mi][h][4 + r]);
+            }
+            *(bf16x8*)(ob + (long)(16 * mt) * p.ldc + 32 * h) = t;
+          }
+      }
+      return;
+    }
+  }
+  // General epilogue.  Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then
+  // the math and the stores - one memory round trip per batch instead of one per 8-column run.
 #pragma unroll
   for (int mb = 0; mb < MT; mb += EB) {
     // pass 1: loads (already in flight since kernel start when PRE)
