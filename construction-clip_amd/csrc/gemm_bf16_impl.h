@@ -537,19 +537,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
         }
       return;
     }
-    if (ACT == CCLIP_ACT_NONE && !PRE && p.out_f32 && p.residual && !p.out_bf16 && !p.out_pre && p.ldr == p.ldc) {
-      // fp32 residual stream: out = alpha*acc + bias + residual (usually in place): out-proj, c_proj
+    if (ACT == CCLIP_ACT_NONE && p.out_f32 && p.residual && !p.out_bf16 && !p.out_pre && p.ldr == p.ldc) {
+      // fp32 residual stream: out = alpha*acc + bias + residual (usually in place): out-proj, c_proj.  The 64x64-per-wave
+      // configurations fetched the residual rows before the K loop (rres); the others load them here, two m-tiles per batch
       const float* rp = p.residual + row0;
       float* of = p.out_f32 + row0;
 #pragma unroll
       for (int mb = 0; mb < MT; mb += 2) {
-        float4 rr[2][2][2];
+        float rr[2][2][8];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const long o = (long)(16 * (mb + mi)) * p.ldc + 32 * h;
-            rr[mi][h][0] = *(const float4*)(rp + o); rr[mi][h][1] = *(const float4*)(rp + o + 4);
+            if (PRE) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) rr[mi][h][r] = rres[PRE ? mb + mi : 0][h][r];
+            } else {
+              const long o = (long)(16 * (mb + mi)) * p.ldc + 32 * h;
+              const float4 t0 = *(const float4*)(rp + o), t1 = *(const float4*)(rp + o + 4);
+              rr[mi][h][0] = t0.x; rr[mi][h][1] = t0.y; rr[mi][h][2] = t0.z; rr[mi][h][3] = t0.w;
+              rr[mi][h][4] = t1.x; rr[mi][h][5] = t1.y; rr[mi][h][6] = t1.z; rr[mi][h][7] = t1.w;
+            }
           }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -557,17 +565,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
           for (int h = 0; h < 2; ++h) {
             const int mt = mb + mi;
             const long o = (long)(16 * mt) * p.ldc + 32 * h;
-            float4 a0, a1;
-            a0.x = acc[mt][2 * h][0] * p.alpha + bsv[h][0] + rr[mi][h][0].x; a0.y = acc[mt][2 * h][1] * p.alpha + bsv[h][1] + rr[mi][h][0].y;
-            a0.z = acc[mt][2 * h][2] * p.alpha + bsv[h][2] + rr[mi][h][0].z; a0.w = acc[mt][2 * h][3] * p.alpha + bsv[h][3] + rr[mi][h][0].w;
-            a1.x = acc[mt][2 * h + 1][0] * p.alpha + bsv[h][4] + rr[mi][h][1].x; a1.y = acc[mt][2 * h + 1][1] * p.alpha + bsv[h][5] + rr[mi][h][1].y;
-            a1.z = acc[mt][2 * h + 1][2] * p.alpha + bsv[h][6] + rr[mi][h][1].z; a1.w = acc[mt][2 * h + 1][3] * p.alpha + bsv[h][7] + rr[mi][h][1].w;
-            *(float4*)(of + o) = a0; *(float4*)(of + o + 4) = a1;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[mt][2 * h][r] * p.alpha + bsv[h][r];
+              v[4 + r] = acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += rr[mi][h][r];
+            *(float4*)(of + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(of + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
           }
       }
       return;
     }
-    if (HAS_AUX && !PRE && p.out_bf16 && !p.out_f32 && !p.out_pre && !p.residual && p.ldaux == p.ldc) {
+    if (HAS_AUX && p.out_bf16 && !p.out_f32 && !p.out_pre && !p.residual && p.ldaux == p.ldc) {
       // activation derivative: out16 = act'(aux) * (alpha*acc + bias): the dgrad of the MLP's second projection
       const bf16* ap = p.aux + row0;
       bf16* ob = p.out_bf16 + row0;
@@ -577,7 +589,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) ax[mi][h] = *(const bf16x8*)(ap + (long)(16 * (mb + mi)) * p.ldc + 32 * h);
+          for (int h = 0; h < 2; ++h)
+            ax[mi][h] = PRE ? raux[(PRE && HAS_AUX) ? mb + mi : 0][h] : *(const bf16x8*)(ap + (long)(16 * (mb + mi)) * p.ldc + 32 * h);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
