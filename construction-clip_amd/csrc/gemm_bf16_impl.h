@@ -212,17 +212,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN_ - 1) / BN_;
-  // Work item = (output tile, K split).  Workgroups are dealt to the 8 XCDs round-robin in LINEAR dispatch order
-  // (blockIdx.x fastest), so with a 2-D grid the XCD of a workgroup is (x + gridDim.x * y) % 8, not x % 8.  Items are
-  // numbered split-major (w = split * tiles + tile) and each XCD takes one contiguous chunk of that order: the ~32 workgroups
-  // an XCD runs at a time then share ONE K range and consecutive tiles, i.e. the 64-row window of dY / X they stream through
-  // together is fetched into that XCD's L2 once instead of once per tile (round-2 PMC: the split-K weight-gradient launches
-  // moved 997 MB per launch at the L2-fabric boundary against 315 MB of operands, at 0.66 of the HBM peak).
-  const int witem = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-  const int bid = witem % gridDim.x, ksplit = witem / gridDim.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int bm0 = (bid / tiles_n) * BM_, bn0 = (bid % tiles_n) * BN_;
   const int nkt = (p.K + BK - 1) / BK;
-  const int kt0 = ksplit * p.ktiles_per_split;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
   const int kt1 = (kt0 + p.ktiles_per_split < nkt) ? kt0 + p.ktiles_per_split : nkt;
   const int wm = wave / WN, wn = wave % WN;
   const int wm0 = wm * 16 * MT, wn0 = wn * 64;                    // offsets inside the block tile
@@ -483,7 +476,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
       for (int mt = 0; mt < MT; ++mt) {
         const int m = bm0 + wm0 + 16 * mt + (lane & 15);
         if (m < p.M) {
-          if (p.split_ws) p.colsum_ws[(long)ksplit * p.M + m] = accb[mt][0];
+          if (p.split_ws) p.colsum_ws[(long)blockIdx.y * p.M + m] = accb[mt][0];
           else p.colsum_dst[m] = (p.colsum_acc ? p.colsum_dst[m] : 0.f) + accb[mt][0];
         }
       }
@@ -496,7 +489,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
           const int n = BPERM ? bn0 + wn0 + 32 * (nt >> 1) + 8 * (lane >> 4) + 4 * (nt & 1) + r
                               : bn0 + wn0 + 16 * nt + 4 * (lane >> 4) + r;
           if (n < p.N) {
-            if (p.split_ws) p.colsum_ws[(long)ksplit * p.N + n] = accb[nt][r];
+            if (p.split_ws) p.colsum_ws[(long)blockIdx.y * p.N + n] = accb[nt][r];
             else p.colsum_dst[n] = (p.colsum_acc ? p.colsum_dst[n] : 0.f) + accb[nt][r];
           }
         }
@@ -635,7 +628,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
         if (p.split_ws) {
-          float* o = p.split_ws + ((long)ksplit * p.M + m) * p.N + n0;
+          float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
           *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
           if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
           continue;
