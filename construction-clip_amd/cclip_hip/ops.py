@@ -548,6 +548,74 @@ def gpt2_decode_step(blocks_arr, n_layer, x, kcache, vcache, pos, scratch16, *, 
     check(_fn("cclip_gpt2_decode_step", kcache)(ctypes.byref(d), _stream()), "cclip_gpt2_decode_step")
 
 
+class BeamDesc(ctypes.Structure):
+    _fields_ = [("step", DecodeDesc),
+                ("n_steps", c_int), ("first", c_int), ("stop_token", c_int), ("ld_tokens", c_int), ("max_len", c_int), ("grid_cap", c_int),
+                ("temperature", c_float),
+                ("first_logits", c_void_p), ("wte_f32", c_void_p), ("wpe_f32", c_void_p),
+                ("slot_of", c_void_p), ("tokens", c_void_p),
+                ("scores", c_void_p), ("seq_lengths", c_void_p), ("is_stopped", c_void_p),
+                ("state", c_void_p), ("select_ws", c_void_p)]
+
+
+BEAM_MAX_BEAMS, BEAM_MAX_LAYERS, BEAM_SELECT_WS_FLOATS = 8, 24, 256 * 8 * 20
+
+
+class BeamState:
+    """Device state of one persistent beam search (cclip_gpt2_beam_search): token rows, scores, lengths, stop flags, the
+    cache-slot table and the kernel's bookkeeping words."""
+
+    def __init__(self, n_beams: int, max_len: int, max_tokens: int, device):
+        assert 1 <= n_beams <= BEAM_MAX_BEAMS
+        self.n_beams, self.max_len = n_beams, max_len
+        self.tokens = torch.zeros(n_beams, max_tokens, device=device, dtype=torch.int32)
+        self.scores = torch.zeros(n_beams, device=device, dtype=torch.float32)
+        self.seq_lengths = torch.ones(n_beams, device=device, dtype=torch.float32)
+        self.is_stopped = torch.zeros(n_beams, device=device, dtype=torch.int32)
+        self.slot_of = torch.zeros(max_len, BEAM_MAX_BEAMS, device=device, dtype=torch.int32)
+        self.state = torch.zeros(8, device=device, dtype=torch.int32)
+        self.select_ws = torch.empty(BEAM_SELECT_WS_FLOATS, device=device, dtype=torch.float32)
+        self.x = None
+
+
+def gpt2_beam_search(blocks_arr, n_layer, st: BeamState, kcache, vcache, pos, scratch16, n_steps, *, heads, hidden, act, lnf_w, lnf_b,
+                     wte16, wte_f32, wpe_f32, temperature, stop_token, first_logits=None, logits=None, grid_cap: int = 0) -> None:
+    """`n_steps` KV-cached decode steps + beam selections in ONE persistent launch (cclip_gpt2_beam_search; Conv1D layout).
+    first_logits ([vocab] fp32, the prefill's last row) given: starts with the one-sequence selection of the first loop
+    iteration.  The cache ([n_layer, n_beams, max_len, width]) holds the prefix in slot 0; beams are reordered through
+    st.slot_of."""
+    nb = st.n_beams
+    D = wte16.shape[1]
+    if st.x is None:
+        st.x = torch.empty(nb, D, device=kcache.device, dtype=torch.float32)
+    assert kcache.dim() == 4 and kcache.shape[1] == nb and kcache.stride(3) == 1 and kcache.stride(2) == D and kcache.stride() == vcache.stride()
+    assert kcache.shape[2] == st.max_len and scratch16.numel() >= nb * (5 * D + hidden) and scratch16.dtype == kcache.dtype
+    assert n_layer <= BEAM_MAX_LAYERS and wte_f32.dtype == torch.float32 and wpe_f32.dtype == torch.float32
+    assert wte_f32.is_contiguous() and wpe_f32.is_contiguous() and wte16.is_contiguous() and wpe_f32.shape[0] >= st.max_len
+    d = BeamDesc()
+    s = d.step
+    s.n_layer, s.n_seq, s.width, s.heads, s.hidden, s.act, s.linear_layout, s.pos = n_layer, nb, D, heads, hidden, act, 0, pos
+    s.blocks = blocks_arr
+    s.x, s.kcache, s.vcache = st.x.data_ptr(), kcache.data_ptr(), vcache.data_ptr()
+    s.ld_layer, s.ld_seq = kcache.stride(0), kcache.stride(1)
+    s.scratch16 = scratch16.data_ptr()
+    s.lnf_w, s.lnf_b, s.wte16, s.vocab = lnf_w.data_ptr(), lnf_b.data_ptr(), wte16.data_ptr(), wte16.shape[0]
+    if logits is not None:
+        _req(logits, torch.float32, "logits")
+        s.logits, s.ld_logits = logits.data_ptr(), logits.stride(0)
+    d.n_steps, d.first, d.stop_token, d.ld_tokens, d.max_len, d.grid_cap = n_steps, int(first_logits is not None), stop_token, st.tokens.stride(0), st.max_len, grid_cap
+    d.temperature = temperature
+    if first_logits is not None:
+        _req(first_logits, torch.float32, "first_logits")
+        assert first_logits.is_contiguous() and first_logits.numel() == wte16.shape[0]
+        d.first_logits = first_logits.data_ptr()
+    d.wte_f32, d.wpe_f32 = wte_f32.data_ptr(), wpe_f32.data_ptr()
+    d.slot_of, d.tokens = st.slot_of.data_ptr(), st.tokens.data_ptr()
+    d.scores, d.seq_lengths, d.is_stopped = st.scores.data_ptr(), st.seq_lengths.data_ptr(), st.is_stopped.data_ptr()
+    d.state, d.select_ws = st.state.data_ptr(), st.select_ws.data_ptr()
+    check(_fn("cclip_gpt2_beam_search", kcache)(ctypes.byref(d), _stream()), "cclip_gpt2_beam_search")
+
+
 # --------------------------------------------------------------------------------------------
 # exact fp32 GEMM:  C = alpha * A @ B^T-like contraction with arbitrary strides
 # --------------------------------------------------------------------------------------------

@@ -5,7 +5,8 @@ The reference calls `model.gpt(inputs_embeds=generated)` on the whole growing se
 position's logits.  Here the prefix is run once (prefill) and every later step feeds ONE token per beam through
 `BlockStack.decode_step` against the cached keys / values; beam reordering gathers the cache.  The selection
 arithmetic on the [beams, V] logits (temperature, softmax-log, length-normalised top-k, nucleus filter) is the
-reference's, restated; it is host-side torch on a few KB and not part of the hot path.
+reference's, restated.  For GPT-2 geometry `generate_beam` runs all of it - decode steps AND selection - inside one persistent
+kernel launch (ClipCaptionModel.beam_search_native); the torch loop below is the same arithmetic and its parity reference.
 
 Not carried over: the attention-map dump that the reference's test.py copy of generate_beam interleaves with decoding
 (`output_attentions=True`, test.py:381-390, `attention_map(...)` :438) - visualisation, SURVEY.md section 8 out of scope.
@@ -30,6 +31,17 @@ def generate_beam(model, tokenizer, beam_size: int = 3, prompt=None, embed=None,
     model.eval()
     device = next(model.parameters()).device
     tokens = None
+    if getattr(model, "beam_native_ok", None) is not None and model.beam_native_ok(beam_size) and entry_length >= 1:
+        # prefill, then ONE persistent kernel for every decode step and every selection (csrc/decode_persist.hip); the
+        # host loop below is the same arithmetic op by op and stays as its parity reference (CCLIP_BEAM_NATIVE=0)
+        if embed is not None:
+            generated = embed
+        else:
+            tokens = torch.tensor(tokenizer.encode(prompt)).unsqueeze(0).to(device)
+            generated = model.gpt.transformer.wte(tokens)
+        tokens, seq_lengths, scores = model.beam_search_native(generated, beam_size, entry_length, temperature, stop_token,
+                                                               prompt_tokens=tokens)
+        return _beam_outputs(tokenizer, tokens, seq_lengths, scores, return_tokens)
     scores = None
     seq_lengths = torch.ones(beam_size, device=device)
     is_stopped = torch.zeros(beam_size, device=device, dtype=torch.bool)
@@ -73,6 +85,11 @@ def generate_beam(model, tokenizer, beam_size: int = 3, prompt=None, embed=None,
         if (step & 3) == 3 or step == entry_length - 1:
             if is_stopped.all():
                 break
+    return _beam_outputs(tokenizer, tokens, seq_lengths, scores, return_tokens)
+
+
+def _beam_outputs(tokenizer, tokens, seq_lengths, scores, return_tokens: bool):
+    """test.py:435-441: length-normalise, order best first, decode each beam up to its length"""
     scores = scores / seq_lengths
     order = scores.argsort(descending=True)
     output_list = tokens.cpu().numpy()

@@ -619,6 +619,60 @@ class ClipCaptionModel(nn.Module):
         cache.length = pos + 1
         return logits.view(B, 1, -1) if logits.is_contiguous() else logits.unsqueeze(1), cache
 
+    def beam_native_ok(self, beam_size: int) -> bool:
+        """the persistent beam-search kernel covers GPT-2 geometry (Conv1D weights, head_dim 64, <= 24 layers) and <= 8 beams"""
+        if os.environ.get("CCLIP_BEAM_NATIVE", "1") == "0" or not 1 <= beam_size <= ops.BEAM_MAX_BEAMS:
+            return False
+        self._ensure_runtime()
+        g, sg = self.model.geo, self._stack.geo
+        V = g.vocab_size
+        return (not sg.linear_layout and g.n_layer <= ops.BEAM_MAX_LAYERS and sg.head_dim == 64 and sg.width % 64 == 0
+                and (sg.hidden or 4 * sg.width) % 32 == 0 and sg.act in (ops.ACT_NONE, ops.ACT_GELU_NEW) and g.n_positions <= 2048
+                and -(-V // 256) <= 256 and next(self.parameters()).is_cuda)
+
+    @torch.no_grad()
+    def beam_search_native(self, inputs_embeds: torch.Tensor, beam_size: int, entry_length: int, temperature: float,
+                           stop_token: int, prompt_tokens: Optional[torch.Tensor] = None, grid_cap: int = 0):
+        """The reference's generate_beam loop (test.py:380-434) after the prefix: prefill here, then every decode step and
+        every selection inside ONE persistent kernel launch (ops.gpt2_beam_search).  Returns (tokens [beams, n] int64,
+        seq_lengths [beams], scores [beams]) exactly where the reference's loop stops (`is_stopped.all()` or entry_length)."""
+        self._ensure_runtime()
+        self._arena.refresh_shadows()
+        g, st = self.model.geo, self._stack
+        B, S, D = inputs_embeds.shape
+        assert B == 1, "beam search starts from one sequence"
+        dev = inputs_embeds.device
+        p = self._arena.params
+        wpe = p["model.transformer.wpe.weight"].data
+        max_len = g.n_positions
+        if S + entry_length - 1 > max_len:
+            raise RuntimeError(f"sequence longer than n_positions = {max_len}")
+        cache = KVCache(g.n_layer, beam_size, max_len, D, dev, self.compute_dtype)
+        x = torch.empty(S, D, device=dev, dtype=torch.float32)
+        ops.add_positional(inputs_embeds.detach().float().contiguous().view(S, D), wpe, x, rows=S, S=S)
+        xo = st.forward(x, 1, T=S, kv_out=(cache.k, cache.v))          # prefix keys / values -> cache slot 0
+        first_logits = self._lm_rows(xo, torch.tensor([S - 1], device=dev, dtype=torch.int32), False)[0].view(-1).float().contiguous()
+        n_prompt = 0 if prompt_tokens is None else int(prompt_tokens.numel())
+        bs = ops.BeamState(beam_size, max_len, n_prompt + entry_length, dev)
+        if n_prompt:
+            bs.tokens[0, :n_prompt] = prompt_tokens.view(-1).to(dev, torch.int32)
+            bs.state[4] = n_prompt
+        if getattr(self, "_decode_ptrs", None) is None or self._decode_ptrs[0] is not self._arena:
+            self._decode_ptrs = (self._arena, ops.block_ptr_array(st.blocks))
+        hidden = st.geo.hidden or 4 * D
+        scratch = torch.empty(beam_size * (5 * D + hidden), device=dev, dtype=self.compute_dtype)
+        ops.gpt2_beam_search(self._decode_ptrs[1], g.n_layer, bs, cache.k, cache.v, S, scratch, entry_length - 1, heads=st.geo.heads,
+                             hidden=hidden, act=st.geo.act, lnf_w=p["model.transformer.ln_f.weight"].data,
+                             lnf_b=p["model.transformer.ln_f.bias"].data, wte16=self._arena.b["model.transformer.wte.weight"],
+                             wte_f32=p["model.transformer.wte.weight"].data, wpe_f32=wpe, temperature=float(temperature),
+                             stop_token=int(stop_token), first_logits=first_logits,
+                             grid_cap=grid_cap or int(os.environ.get("CCLIP_BEAM_GRID", "0")))
+        state = bs.state.tolist()                                       # the one host sync of the caption
+        if state[1]:
+            raise RuntimeError("cclip_gpt2_beam_search: a grid barrier timed out (workgroups not co-resident?)")
+        n_sel = state[3] if state[2] else entry_length
+        return bs.tokens[:, :n_prompt + n_sel].long(), bs.seq_lengths, bs.scores
+
     def _embed_and_run(self, tokens, prefix, attribute, mask, train: bool):
         self._ensure_runtime()
         ar = self._arena

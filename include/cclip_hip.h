@@ -303,6 +303,38 @@ typedef struct cclip_decode_desc {
 } cclip_decode_desc;
 int cclip_gpt2_decode_step(const cclip_decode_desc* d, hipStream_t stream);
 
+/* ---- persistent KV-cached beam search -------------------------------------------------------------
+ * Replaces the body of the reference's generate_beam loop (CLIP_prefix_caption/test.py:380-434, application.py:176-222:
+ * `model.gpt(inputs_embeds=generated)` on the growing sequence, temperature, softmax(-1).log(), the stopped-beam rule,
+ * length-normalised top-k over [beams x vocab], token append, beam reorder, next-token embedding) with ONE kernel launch for
+ * `n_steps` decode steps: one workgroup per CU, phases separated by a grid barrier (csrc/decode_persist.hip).
+ * step: as for cclip_gpt2_decode_step (Conv1D weight layout only, n_seq = beam count <= 8, n_layer <= 24, head_dim 64);
+ *   step.pos = position of the first token to be decoded (= length of the prefilled prefix); step.x is written by the
+ *   selection (token embedding + position embedding of the chosen tokens) and need not be initialised when first = 1;
+ *   step.logits (optional, fp32 [n_seq, ld_logits]) receives each step's logits.
+ * first = 1: `first_logits` [vocab] are the prefill's last-position logits and the first selection is the one-sequence form
+ *   (test.py:396-405: top-k of one row, scores = its log-probabilities); the key / value rows of the prefix must be in cache
+ *   slot 0 and `slot_of` zero.  first = 0 continues a search from the state the previous call left.
+ * slot_of: int32 [max_len][8]: cache slot holding beam b's key / value of position t (beam reorder permutes this table; the
+ *   cache itself is never copied).  tokens: int32 [n_seq][ld_tokens], state[4] columns valid on entry (prompt tokens of row 0
+ *   when first = 1) - one more per selection.  scores / seq_lengths / is_stopped: [n_seq] (written when first = 1).
+ * state: int32 [8]: [0] barrier counter and [1] error flag (cleared by every call; error = a grid barrier timed out),
+ *   [2] set once every beam has stopped, [3] number of selections made by then (the reference's loop breaks there),
+ *   [4] token columns.  Zero [2..4] (or set [4] to the prompt length) before the first call.
+ * select_ws: fp32 [256 * 8 * 20].  grid_cap: 0, or a cap on the number of workgroups (tests).
+ * After every beam has stopped the remaining steps are skipped (the kernel exits); results are those of the loop's break. */
+typedef struct cclip_beam_desc {
+  cclip_decode_desc step;
+  int32_t n_steps, first, stop_token, ld_tokens, max_len, grid_cap;
+  float temperature;
+  const float* first_logits;
+  const float* wte_f32; const float* wpe_f32;
+  int32_t* slot_of; int32_t* tokens;
+  float* scores; float* seq_lengths; int32_t* is_stopped;
+  int32_t* state; float* select_ws;
+} cclip_beam_desc;
+int cclip_gpt2_beam_search(const cclip_beam_desc* d, hipStream_t stream);
+
 /* ---- IEEE fp16 twins ---------------------------------------------------------------------------
  * Every entry point above whose 16-bit buffers are bf16 has a twin with the identical signature that
  * treats them as IEEE fp16 (same MFMA rate on gfx950; 3 more mantissa bits - the reference's own CUDA
@@ -330,6 +362,7 @@ int cclip_xent_rows_f16(const float* logits, int64_t ld, int32_t R, int32_t C, c
                         int32_t ignore_index, float grad_scale, float* loss_row, int32_t* pred,
                         void* dlogits, int32_t dlogits_is_f16, int64_t ldd, float* rowdot, hipStream_t stream);
 int cclip_gpt2_decode_step_f16(const cclip_decode_desc* d, hipStream_t stream);
+int cclip_gpt2_beam_search_f16(const cclip_beam_desc* d, hipStream_t stream);
 int cclip_quantize_rows_fp8_f16(const void* x_f16, int64_t ldx, int32_t rows, int32_t cols, void* out_fp8, int64_t ldo,
                                 float* scale, hipStream_t stream);
 int cclip_gemm_fp8_f16(const void* A8, int64_t lda, const float* scale_a, const void* B8, int64_t ldb, const float* scale_b,

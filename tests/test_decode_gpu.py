@@ -156,3 +156,41 @@ def test_generate_beam_and_generate2_at_gpt2_small_geometry():
     rt2, _ = CO.generate2_tokens(sd, ref_emb, geo.n_head, entry_length=steps, stop_token=102)
     _, tok2 = generate2(model, _Tok(), embed=emb, entry_length=steps, stop_token=102, return_tokens=True)
     assert torch.equal(tok2.cpu(), rt2), (tok2.cpu(), rt2)
+
+
+@pytest.mark.parametrize("half,beam,stop,grid_cap,use_prompt", [(True, 3, 7, 0, False), (False, 3, 7, 0, False), (True, 1, 7, 0, False),
+                                                               (True, 5, 26, 0, False), (True, 3, -1, 8, False), (True, 8, 7, 3, False),
+                                                               (True, 3, 7, 0, True)])
+def test_persistent_beam_search_equals_host_loop(monkeypatch, half, beam, stop, grid_cap, use_prompt):
+    """cclip_gpt2_beam_search (every decode step and every selection of a caption inside one persistent kernel; beam reorder
+    through the cache-slot table) against the torch loop of clip_caption/generate.py, which is the reference's loop
+    (test.py:380-434) op by op on the launch-by-launch decode step: same tokens inside every beam's length, same lengths, scores
+    to rounding.  grid_cap exercises the strided phase loops with fewer workgroups than column blocks."""
+    from clip_caption import generate_beam
+    geo, sd, model, prefix, attribute = _model(half=half)
+    emb = _prefix_embed(model, geo, prefix, attribute)
+    kw = dict(beam_size=beam, entry_length=14, stop_token=stop, return_tokens=True)
+    if use_prompt:
+        kw["prompt"] = "5 9 11 3"
+    else:
+        kw["embed"] = emb
+    monkeypatch.setenv("CCLIP_BEAM_NATIVE", "0")
+    _, t0, l0, s0 = generate_beam(model, _Tok(), **kw)
+    monkeypatch.setenv("CCLIP_BEAM_NATIVE", "1")
+    assert model.beam_native_ok(beam)
+    if grid_cap:
+        gen = emb if not use_prompt else None
+        t1, l1, s1 = model.beam_search_native(gen, beam, 14, 0.5, stop, grid_cap=grid_cap)
+        s1 = s1 / l1
+    else:
+        _, t1, l1, s1 = generate_beam(model, _Tok(), **kw)
+    assert torch.equal(l0.cpu(), l1.cpu()), (l0, l1)
+    assert (s0 - s1).abs().max() < 2e-3, (s0, s1)
+    n = min(t0.shape[1], t1.shape[1])
+    npr = 4 if use_prompt else 0
+    assert t1.shape[1] <= t0.shape[1]                     # the host loop looks for "all stopped" every 4th step only
+    for b in range(beam):
+        keep = npr + int(l1[b])
+        assert torch.equal(t0[b, :min(keep, n)].cpu(), t1[b, :min(keep, n)].cpu()), (b, t0, t1)
+    if stop == -1:
+        assert t1.shape[1] == npr + 14                    # never stops: every selection made
