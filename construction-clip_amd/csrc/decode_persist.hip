@@ -44,17 +44,24 @@ struct BeamArgs {
   float* part;
 };
 
-// ---- grid barrier ------------------------------------------------------------------------------------------------------
-struct GridSync {
-  int* counter; int* err; int target; int G; bool dead;
+// ---- phase hand-over --------------------------------------------------------------------------------------------------
+// One monotonic counter.  A phase's PRODUCERS (the workgroups that had a column block / task / slice in it) add 1 when their
+// part is written; every workgroup keeps the same running total of producers (`target`), and a workgroup waits for that total
+// only when it is about to work in the next phase.  Idle workgroups neither add nor poll: with 24-96 of 256 workgroups active
+// in a projection phase, a full barrier's 256 serialized atomics and 256 pollers were most of its 2-5 us.
+// (The phase's hand-over buffers are written with write-through sc1 stores and read with sc1 loads - st_coh / ld_coh - so no
+// cache-wide write-back / invalidate is needed: a release + acquire fence pair per workgroup per phase cost ~30 us per phase.)
+struct PhaseSync {
+  int* counter; int* err; int target; bool dead;
+  // end of a phase that `nprod` workgroups worked in; `worked`: this workgroup was one of them
+  __device__ __forceinline__ void arrive(int nprod, bool worked) {
+    __syncthreads();                                               // every wave's stores of the phase are out (vmcnt(0) + barrier)
+    target += nprod;
+    if (worked && !dead && threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // before reading what the phases so far produced
   __device__ __forceinline__ void wait() {
-    __syncthreads();
-    target += G;
-    // (the __syncthreads above waited for every wave's outstanding stores; the phase's hand-over buffers are written with
-    // write-through sc1 stores and read with sc1 loads - st_coh / ld_coh - so no cache-wide write-back / invalidate is needed:
-    // a release + acquire fence pair per workgroup per barrier cost ~30 us per phase with 256 workgroups)
     if (!dead && threadIdx.x == 0) {
-      __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
       while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
@@ -164,7 +171,7 @@ __device__ __forceinline__ void attn_task(const BeamArgs& a, const bf16* q, long
 
 // ---- per-beam partials of one vocabulary slice (sl: [n_in][BEAM_MAXR] logits of rows r0..r0+nr) ----------------------------
 // wave w handles beams w, w+4: slice max and sum-exp of z = logit / T, and the slice's top-k by z (k = a.nb)
-__device__ __forceinline__ void select_partials(const BeamArgs& a, const float* sl, int n_in, int r0, int nr, float inv_t_is_div) {
+__device__ __noinline__ void select_partials(const BeamArgs& a, const float* sl, int n_in, int r0, int nr, float inv_t_is_div) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float T = inv_t_is_div;
   for (int m = wave; m < n_in; m += 4) {
@@ -200,7 +207,7 @@ __device__ __forceinline__ void select_partials(const BeamArgs& a, const float* 
 }
 
 // ---- the selection proper, by workgroup 0 (256 threads); lds: 64 + 512 + 4096 + 2 * n_in*G*k floats -------------------------------
-__device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool first, int it, int cur_pos, int G, float* lds) {
+__device__ __noinline__ void select_merge(const BeamArgs& a, int n_in, bool first, int it, int cur_pos, int G, int ntok, float* lds) {
   const int tid = threadIdx.x;
   const int nb = a.nb, k = a.nb;
   float* bM = lds;            // [8] global max per beam
@@ -229,22 +236,36 @@ __device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool f
     for (int m = 0; m < 8; ++m) { stat[m * 512 + tid] = tid < G ? pm[m] : -__builtin_inff(); stat[m * 512 + 256 + tid] = tid < G ? ps[m] : 0.f; }
   }
   __syncthreads();
-  if (tid < 8 && tid < n_in) {
-    float M = -__builtin_inff();
-    for (int g = 0; g < G; ++g) M = fmaxf(M, stat[tid * 512 + g]);
-    bM[tid] = M;
-  }
-  __syncthreads();
+  {
+    // block max / sum by wave shuffles + the four waves' results through LDS (fixed order: reproducible)
+    const int lane = tid & 63, wave = tid >> 6;
+    float wm[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
-    if (m < n_in) { const float sg = stat[m * 512 + 256 + tid]; stat[m * 512 + 256 + tid] = sg > 0.f ? sg * expf(stat[m * 512 + tid] - bM[m]) : 0.f; }
-  __syncthreads();
+    for (int m = 0; m < 8; ++m) wm[m] = wave_max(stat[m * 512 + tid]);
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) red_v[wave * 8 + m] = wm[m];
+    }
+    __syncthreads();
+    if (tid < 8) bM[tid] = fmaxf(fmaxf(red_v[tid], red_v[8 + tid]), fmaxf(red_v[16 + tid], red_v[24 + tid]));
+    __syncthreads();
+    float ws[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float sg = stat[m * 512 + 256 + tid];
+      ws[m] = wave_sum(sg > 0.f ? sg * expf(stat[m * 512 + tid] - bM[m]) : 0.f);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) red_v[wave * 8 + m] = ws[m];
+    }
+    __syncthreads();
+  }
   if (tid < 8) {
     const int m = tid;
     if (m < n_in) {
-      float S = 0.f;
-      for (int g = 0; g < G; ++g) S += stat[m * 512 + 256 + g];
-      bS[m] = S;
+      bS[m] = ((red_v[m] + red_v[8 + m]) + red_v[16 + m]) + red_v[24 + m];
       const bool st = first ? false : a.stopped[m] != 0;
       o_st[m] = st ? 1 : 0;
       o_sc[m] = first ? 0.f : a.scores[m];
@@ -253,10 +274,10 @@ __device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool f
   }
   __syncthreads();
   const int C = n_in * G * k;
-  for (int c0 = tid; c0 < C; c0 += 1024) {                          // candidates: four per thread in flight
-    float zz[4]; int tk[4];
+  for (int c0 = tid; c0 < C; c0 += 3072) {                          // candidates: twelve per thread in flight
+    float zz[12]; int tk[12];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 12; ++u) {
       const int c = c0 + 256 * u < C ? c0 + 256 * u : C - 1;
       const int r = c % k, g = (c / k) % G, m = c / (k * G);
       const float* pp = a.part + ((long)g * 8 + m) * BEAM_PS;
@@ -264,7 +285,7 @@ __device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool f
       tk[u] = ld_coh<true>((const int*)pp + 3 + 2 * r);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 12; ++u) {
       const int c = c0 + 256 * u;
       if (c >= C) continue;
       const int r = c % k, g = (c / k) % G, m = c / (k * G);
@@ -290,14 +311,20 @@ __device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool f
       const float v = cav[c]; const int f = cfl[c];
       if (f != 0x7fffffff && (bc < 0 || v > bv || (v == bv && f < bf))) { bv = v; bc = c; bf = f; }
     }
-    red_v[tid] = bv; red_i[tid] = bc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                              // wave arg-max: larger average, then the lower flat index
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oc = __shfl_xor(bc, o, 64), of = __shfl_xor(bf, o, 64);
+      if (oc >= 0 && (bc < 0 || ov > bv || (ov == bv && of < bf))) { bv = ov; bc = oc; bf = of; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bc; red_i[4 + (tid >> 6)] = bf; }
     __syncthreads();
     if (tid == 0) {
       float v0 = -__builtin_inff(); int c0 = -1, f0 = 0x7fffffff;
-      for (int t = 0; t < 256; ++t) {
+      for (int t = 0; t < 4; ++t) {
         const int cc = red_i[t];
         if (cc < 0) continue;
-        const float v = red_v[t]; const int f = cfl[cc];
+        const float v = red_v[t]; const int f = red_i[4 + t];
         if (c0 < 0 || v > v0 || (v == v0 && f < f0)) { v0 = v; c0 = cc; f0 = f; }
       }
       w_avg[r] = v0; w_flat[r] = c0 >= 0 ? f0 : 0;
@@ -313,8 +340,44 @@ __device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool f
     src[i] = f / a.V; tok[i] = f % a.V;
     if (src[i] >= n_in) src[i] = n_in - 1;
   }
-  const int ntok = a.state[4];
-  for (int j = tid; j < ntok; j += 256) {                           // tokens = cat(tokens[next_tokens_source], next_tokens)
+  // every load of the bookkeeping goes out first (token rows, slot-table rows, embedding rows: unconditional, clamped
+  // addresses), then the stores: issued phase by phase this was ~8 dependent memory round trips
+  const int next_pos = first ? a.pos0 : cur_pos + 1;
+  const bool has_next = next_pos < a.max_len;
+  int told[8], sold[8];
+  float e[8][4], pe[4];
+  {
+    const int j = tid < ntok ? tid : 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) told[m] = a.tokens[(long)(m < n_in ? m : 0) * a.ld_tokens + j];
+    const int t = tid <= cur_pos ? tid : 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) sold[m] = ld_coh<true>(a.slot_of + (long)(t < 0 ? 0 : t) * 8 + m);
+    const int np = has_next ? next_pos : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int d = tid + 256 * u < a.D ? tid + 256 * u : 0;
+      pe[u] = a.wpe32[(long)np * a.D + d];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i][u] = a.wte32[(long)tok[i < nb ? i : 0] * a.D + d];
+    }
+  }
+  if (tid < ntok) {                                                 // tokens = cat(tokens[next_tokens_source], next_tokens)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < nb) a.tokens[(long)i * a.ld_tokens + tid] = told[src[i]];
+  }
+  if (!first && tid <= cur_pos) {                                   // cache reorder = permute the slot table
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < nb) st_coh<true>(a.slot_of + (long)tid * 8 + i, sold[src[i]]);
+  }
+  if (has_next) {
+    if (tid < nb) st_coh<true>(a.slot_of + (long)next_pos * 8 + tid, tid);        // the next step appends beam b's row to slot b
+#pragma unroll
+    for (int i = 0; i < 8; ++i)                                     // next input: wte[token] + wpe[position] (D <= 1024: 4 per thread)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i < nb && tid + 256 * u < a.D) st_coh<true>(a.x + (long)i * a.D + tid + 256 * u, e[i][u] + pe[u]);
+  }
+  for (int j = tid + 256; j < ntok; j += 256) {                     // (prompts longer than 256 tokens)
     int old[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) old[m] = m < n_in ? a.tokens[(long)m * a.ld_tokens + j] : 0;
@@ -322,26 +385,12 @@ __device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool f
     for (int i = 0; i < 8; ++i) if (i < nb) a.tokens[(long)i * a.ld_tokens + j] = old[src[i]];
   }
   if (!first) {
-    for (int t = tid; t <= cur_pos; t += 256) {                     // cache reorder = permute the slot table
+    for (int t = tid + 256; t <= cur_pos; t += 256) {               // (positions past 256)
       int old[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) old[m] = ld_coh<true>(a.slot_of + (long)t * 8 + m);
 #pragma unroll
       for (int i = 0; i < 8; ++i) if (i < nb) st_coh<true>(a.slot_of + (long)t * 8 + i, old[src[i]]);
-    }
-  }
-  const int next_pos = first ? a.pos0 : cur_pos + 1;
-  if (next_pos < a.max_len) {
-    if (tid < nb) st_coh<true>(a.slot_of + (long)next_pos * 8 + tid, tid);        // the next step appends beam b's row to slot b
-    for (int i = 0; i < nb; ++i) {                                  // next input: wte[token] + wpe[position] (D <= 1024: 4 per thread)
-      float e[4], pe[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int d = tid + 256 * u < a.D ? tid + 256 * u : 0;
-        e[u] = a.wte32[(long)tok[i] * a.D + d]; pe[u] = a.wpe32[(long)next_pos * a.D + d];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) if (tid + 256 * u < a.D) st_coh<true>(a.x + (long)i * a.D + tid + 256 * u, e[u] + pe[u]);
     }
   }
   __syncthreads();
@@ -362,82 +411,13 @@ __device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool f
   __syncthreads();
 }
 
+// LN_f + tied lm_head over the vocabulary slice [r0, r0 + nr): xs = LN_f(x) rounded to the operand type, fp32 [nb][D] at lds;
+// the slice's logits go to sl = lds + MCAP*D as [nb][BEAM_MAXR] (and to a.logits when given)
 template <int MCAP>
-__global__ __launch_bounds__(256) void gpt2_beam_persist_kernel(const BeamArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void head_phase(const BeamArgs& a, float* lds, int r0, int nr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = gridDim.x, D = a.D, Hd = a.Hd, nb = a.nb;
-  GridSync gs{a.state, a.state + 1, 0, G, false};
-  const long ldrow = 5L * D + Hd;
-  bf16* qkv = a.scratch + D;
-  bf16* att = a.scratch + 4L * D;
-  bf16* hid = a.scratch + 5L * D;
-  const float T = a.temperature > 0.f ? a.temperature : 1.0f;
-  const int R = a.rows_per_wg;
-  const int r0 = blockIdx.x * R;
-  const int nr = r0 >= a.V ? 0 : (a.V - r0 < R ? a.V - r0 : R);
-  int it = 0;
-  if (a.first) {
-    // the prefill's last-position logits: selection with one input beam (test.py:396-405)
-    for (int j = tid; j < nr; j += 256) lds[j] = a.first_logits[r0 + j];
-    __syncthreads();
-    select_partials(a, lds, 1, r0, nr, T);
-    gs.wait();
-    if (blockIdx.x == 0) select_merge(a, 1, true, it, a.pos0 - 1, G, lds);
-    gs.wait();
-    ++it;
-  }
-  for (int s = 0; s < a.n_steps; ++s, ++it) {
-    if (__hip_atomic_load(a.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;     // every beam has stopped
-    const int pos = a.pos0 + s;
-    if (pos >= a.max_len) break;
-    GemmArgs p;
-    p.alpha = 1.0f; p.aux = nullptr; p.ldaux = 0; p.out_pre = nullptr; p.split_ws = nullptr; p.ktiles_per_split = 0; p.M = nb;
-    for (int l = 0; l < a.n_layer; ++l) {
-      const cclip_block_ptrs& w = a.blocks[l];
-      bf16* kc = a.kc + (long)l * a.ld_layer;
-      bf16* vc = a.vc + (long)l * a.ld_layer;
-      // P1: LayerNorm + qkv projection, k / v appended at `pos` of each beam's own slot
-      p.A = nullptr; p.lda = 0; p.B = (const bf16*)w.w_qkv; p.ldb = 3 * D; p.N = 3 * D; p.K = D; p.bias = w.b_qkv; p.act = 0;
-      p.residual = nullptr; p.ldr = 0; p.out_f32 = nullptr; p.out_bf16 = qkv; p.ldc = ldrow;
-      p.ln_x = a.x; p.ln_ldx = D; p.ln_gamma = w.ln1_w; p.ln_beta = w.ln1_b;
-      p.kv_k = kc + (long)pos * D; p.kv_v = vc + (long)pos * D; p.kv_ld_seq = a.ld_seq; p.kv_width = D;
-      for (int cb = blockIdx.x; cb * 32 < 3 * D; cb += G) skinny_block<MCAP, CCLIP_ACT_NONE, 12, true>(p, cb * 32, lds);
-      gs.wait();
-      // P2: attention of the new token against positions [0, pos]
-      for (int t0 = blockIdx.x * 4; t0 < nb * a.H; t0 += G * 4) {
-        const int t = t0 + wave;
-        const bool valid = t < nb * a.H;
-        const int tt = valid ? t : nb * a.H - 1;
-        float* wl = lds + wave * (128 + a.max_len + 64);           // per wave: 128 probabilities, max_len row offsets, 64 q
-        attn_task(a, qkv, ldrow, kc, vc, att, ldrow, tt / a.H, tt % a.H, pos + 1, valid, wl, (int*)(wl + 128), wl + 128 + a.max_len);
-      }
-      gs.wait();
-      // P3: out-proj + residual (x += ...)
-      p.ln_x = nullptr; p.kv_k = nullptr; p.kv_v = nullptr; p.kv_width = 0;
-      p.A = att; p.lda = ldrow; p.B = (const bf16*)w.w_o; p.ldb = D; p.N = D; p.K = D; p.bias = w.b_o;
-      p.residual = a.x; p.ldr = D; p.out_f32 = a.x; p.out_bf16 = nullptr; p.ldc = D;
-      for (int cb = blockIdx.x; cb * 32 < D; cb += G) skinny_block<MCAP, CCLIP_ACT_NONE, 12, true>(p, cb * 32, lds);
-      gs.wait();
-      // P4: LayerNorm + fc + activation
-      p.A = nullptr; p.lda = 0; p.B = (const bf16*)w.w_fc; p.ldb = Hd; p.N = Hd; p.K = D; p.bias = w.b_fc;
-      p.residual = nullptr; p.ldr = 0; p.out_f32 = nullptr; p.out_bf16 = hid; p.ldc = ldrow;
-      p.ln_x = a.x; p.ln_ldx = D; p.ln_gamma = w.ln2_w; p.ln_beta = w.ln2_b;
-      if (a.act == CCLIP_ACT_GELU_NEW) {
-        for (int cb = blockIdx.x; cb * 32 < Hd; cb += G) skinny_block<MCAP, CCLIP_ACT_GELU_NEW, 12, true>(p, cb * 32, lds);
-      } else {
-        for (int cb = blockIdx.x; cb * 32 < Hd; cb += G) skinny_block<MCAP, CCLIP_ACT_NONE, 12, true>(p, cb * 32, lds);
-      }
-      gs.wait();
-      // P5: proj + residual
-      p.ln_x = nullptr;
-      p.A = hid; p.lda = ldrow; p.B = (const bf16*)w.w_proj; p.ldb = D; p.N = D; p.K = Hd; p.bias = w.b_proj;
-      p.residual = a.x; p.ldr = D; p.out_f32 = a.x; p.out_bf16 = nullptr; p.ldc = D;
-      for (int cb = blockIdx.x; cb * 32 < D; cb += G) skinny_block<MCAP, CCLIP_ACT_NONE, 16, true>(p, cb * 32, lds);
-      gs.wait();
-    }
-    // LN_f + tied lm_head over this workgroup's vocabulary slice [r0, r0 + nr), then the slice's selection partials.
-    // xs: LN_f(x) rounded to the operand type, fp32 [nb][D]; sl: the slice's logits [nb][BEAM_MAXR]
+  const int D = a.D, nb = a.nb;
+  {
     float* xs = lds;
     float* sl = lds + MCAP * D;
     for (int m = wave; m < nb; m += 4) {                              // (D <= 1024 checked by the launcher: one read of the row)
@@ -461,47 +441,46 @@ __global__ __launch_bounds__(256) void gpt2_beam_persist_kernel(const BeamArgs a
     }
     __syncthreads();
     {
-      // lane (r = lane >> 4, c = lane & 15): vocabulary row r of the wave's 4, 16-byte chunks c, c + 16, ...; two row groups
-      // (32 rows per workgroup) are in flight together
+      // lane (r = lane >> 4, c = lane & 15): vocabulary row r of the wave's 4, 16-byte chunks c, c + 16, ... (D <= 1024: up to
+      // 4 per lane per half); 48 rows of the slice per trip with every load of the trip in flight (8 x 16 bytes per lane
+      // per half-row pass): the slice is weight-read latency, not bandwidth
       const int rr = lane >> 4, c16 = lane & 15;
       const int nch = D >> 3;                                       // 16-byte chunks per row
-      for (int g0 = 0; g0 < nr; g0 += 32) {
-        float acc[2][MCAP];
+      for (int g0 = 0; g0 < nr; g0 += 48) {
+        float acc[3][MCAP];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 3; ++h)
 #pragma unroll
           for (int m = 0; m < MCAP; ++m) acc[h][m] = 0.f;
-        for (int c0 = 0; c0 < nch; c0 += 64) {                      // 4 chunks per lane per trip (D = 768: 6 -> two trips)
-          bf16x8 wv[2][4];
+        bf16x8 wv[3][8];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int row = g0 + 16 * h + 4 * wave + rr;
-            const bf16* wr = a.wte16 + (long)(r0 + (row < nr ? row : nr - 1)) * D;
+        for (int h = 0; h < 3; ++h) {
+          const int row = g0 + 16 * h + 4 * wave + rr;
+          const bf16* wr = a.wte16 + (long)(r0 + (row < nr ? row : nr - 1)) * D;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int ch = c0 + c16 + 16 * u;
-              wv[h][u] = *(const bf16x8*)(wr + 8 * (ch < nch ? ch : nch - 1));
-            }
+          for (int u = 0; u < 8; ++u) {
+            const int ch = c16 + 16 * u;
+            wv[h][u] = *(const bf16x8*)(wr + 8 * (ch < nch ? ch : nch - 1));
           }
+        }
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 3; ++h)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int ch = c0 + c16 + 16 * u;
-              if (ch < nch) {
+          for (int u = 0; u < 8; ++u) {
+            const int ch = c16 + 16 * u;
+            if (ch < nch) {
 #pragma unroll
-                for (int m = 0; m < MCAP; ++m) {
-                  if (m < nb) {
-                    const float* xm = xs + m * D + 8 * ch;
+              for (int m = 0; m < MCAP; ++m) {
+                if (m < nb) {
+                  const float* xm = xs + m * D + 8 * ch;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[h][m] += xm[j] * (float)wv[h][u][j];
-                  }
+                  for (int j = 0; j < 8; ++j) acc[h][m] += xm[j] * (float)wv[h][u][j];
                 }
               }
             }
-        }
+          }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 3; ++h) {
           const int row = g0 + 16 * h + 4 * wave + rr;
 #pragma unroll
           for (int m = 0; m < MCAP; ++m) {
@@ -515,11 +494,114 @@ __global__ __launch_bounds__(256) void gpt2_beam_persist_kernel(const BeamArgs a
         }
       }
     }
+  }
+}
+
+// one projection phase: this workgroup's column blocks
+template <int MCAP, int ACT, int U>
+__device__ __forceinline__ void proj_phase(const GemmArgs& p, int nblk, int G, float* lds, PhaseSync* ps) {
+  auto pw = [&]() { ps->wait(); };           // (waiting twice for the same total is free: the second call returns at once)
+  for (int cb = blockIdx.x; cb < nblk; cb += G) skinny_block<MCAP, ACT, U, true>(p, cb * 32, lds, pw);
+}
+
+template <int MCAP>
+__global__ __launch_bounds__(256) void gpt2_beam_persist_kernel(const BeamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = gridDim.x, D = a.D, Hd = a.Hd, nb = a.nb;
+  PhaseSync ps{a.state, a.state + 1, 0, false};
+  auto nprod = [&](int nblk) { return nblk < G ? nblk : G; };
+  const long ldrow = 5L * D + Hd;
+  bf16* qkv = a.scratch + D;
+  bf16* att = a.scratch + 4L * D;
+  bf16* hid = a.scratch + 5L * D;
+  const float T = a.temperature > 0.f ? a.temperature : 1.0f;
+  const int R = a.rows_per_wg;
+  const int r0 = blockIdx.x * R;
+  const int nr = r0 >= a.V ? 0 : (a.V - r0 < R ? a.V - r0 : R);
+  int it = 0;
+  const int ntok0 = a.state[4];                                    // token columns present at launch; one more per selection
+  if (a.first) {
+    // the prefill's last-position logits: selection with one input beam (test.py:396-405)
+    for (int j = tid; j < nr; j += 256) lds[j] = a.first_logits[r0 + j];
+    __syncthreads();
+    select_partials(a, lds, 1, r0, nr, T);
+    ps.arrive(G, true);
+    if (blockIdx.x == 0) { ps.wait(); select_merge(a, 1, true, it, a.pos0 - 1, G, ntok0 + it, lds); }
+    ps.arrive(1, blockIdx.x == 0);
+    ++it;
+  }
+  for (int s = 0; s < a.n_steps; ++s, ++it) {
+    ps.wait();                                                      // the selection: next input rows, slot table, the stop flag
+    if (__hip_atomic_load(a.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;     // every beam has stopped
+    const int pos = a.pos0 + s;
+    if (pos >= a.max_len) break;
+    GemmArgs p;
+    p.alpha = 1.0f; p.aux = nullptr; p.ldaux = 0; p.out_pre = nullptr; p.split_ws = nullptr; p.ktiles_per_split = 0; p.M = nb;
+    for (int l = 0; l < a.n_layer; ++l) {
+      const cclip_block_ptrs& w = a.blocks[l];
+      bf16* kc = a.kc + (long)l * a.ld_layer;
+      bf16* vc = a.vc + (long)l * a.ld_layer;
+      // P1: LayerNorm + qkv projection, k / v appended at `pos` of each beam's own slot
+      p.A = nullptr; p.lda = 0; p.B = (const bf16*)w.w_qkv; p.ldb = 3 * D; p.N = 3 * D; p.K = D; p.bias = w.b_qkv; p.act = 0;
+      p.residual = nullptr; p.ldr = 0; p.out_f32 = nullptr; p.out_bf16 = qkv; p.ldc = ldrow;
+      p.ln_x = a.x; p.ln_ldx = D; p.ln_gamma = w.ln1_w; p.ln_beta = w.ln1_b;
+      p.kv_k = kc + (long)pos * D; p.kv_v = vc + (long)pos * D; p.kv_ld_seq = a.ld_seq; p.kv_width = D;
+      {
+        const int nblk = (3 * D + 31) / 32;
+        proj_phase<MCAP, CCLIP_ACT_NONE, 12>(p, nblk, G, lds, &ps);
+        ps.arrive(nprod(nblk), blockIdx.x < nblk);
+      }
+      // P2: attention of the new token against positions [0, pos]
+      const int ntask4 = (nb * a.H + 3) / 4;
+      if (blockIdx.x < ntask4) ps.wait();
+      for (int t0 = blockIdx.x * 4; t0 < nb * a.H; t0 += G * 4) {
+        const int t = t0 + wave;
+        const bool valid = t < nb * a.H;
+        const int tt = valid ? t : nb * a.H - 1;
+        float* wl = lds + wave * (128 + a.max_len + 64);           // per wave: 128 probabilities, max_len row offsets, 64 q
+        attn_task(a, qkv, ldrow, kc, vc, att, ldrow, tt / a.H, tt % a.H, pos + 1, valid, wl, (int*)(wl + 128), wl + 128 + a.max_len);
+      }
+      ps.arrive(nprod(ntask4), blockIdx.x < ntask4);
+      // P3: out-proj + residual (x += ...)
+      p.ln_x = nullptr; p.kv_k = nullptr; p.kv_v = nullptr; p.kv_width = 0;
+      p.A = att; p.lda = ldrow; p.B = (const bf16*)w.w_o; p.ldb = D; p.N = D; p.K = D; p.bias = w.b_o;
+      p.residual = a.x; p.ldr = D; p.out_f32 = a.x; p.out_bf16 = nullptr; p.ldc = D;
+      {
+        const int nblk = (D + 31) / 32;
+        proj_phase<MCAP, CCLIP_ACT_NONE, 12>(p, nblk, G, lds, &ps);
+        ps.arrive(nprod(nblk), blockIdx.x < nblk);
+      }
+      // P4: LayerNorm + fc + activation
+      p.A = nullptr; p.lda = 0; p.B = (const bf16*)w.w_fc; p.ldb = Hd; p.N = Hd; p.K = D; p.bias = w.b_fc;
+      p.residual = nullptr; p.ldr = 0; p.out_f32 = nullptr; p.out_bf16 = hid; p.ldc = ldrow;
+      p.ln_x = a.x; p.ln_ldx = D; p.ln_gamma = w.ln2_w; p.ln_beta = w.ln2_b;
+      {
+        const int nblk = (Hd + 31) / 32;
+        if (a.act == CCLIP_ACT_GELU_NEW) proj_phase<MCAP, CCLIP_ACT_GELU_NEW, 12>(p, nblk, G, lds, &ps);
+        else proj_phase<MCAP, CCLIP_ACT_NONE, 12>(p, nblk, G, lds, &ps);
+        ps.arrive(nprod(nblk), blockIdx.x < nblk);
+      }
+      // P5: proj + residual
+      p.ln_x = nullptr;
+      p.A = hid; p.lda = ldrow; p.B = (const bf16*)w.w_proj; p.ldb = D; p.N = D; p.K = Hd; p.bias = w.b_proj;
+      p.residual = a.x; p.ldr = D; p.out_f32 = a.x; p.out_bf16 = nullptr; p.ldc = D;
+      {
+        const int nblk = (D + 31) / 32;
+        proj_phase<MCAP, CCLIP_ACT_NONE, 16>(p, nblk, G, lds, &ps);
+        ps.arrive(nprod(nblk), blockIdx.x < nblk);
+      }
+    }
+    // LN_f + tied lm_head over this workgroup's vocabulary slice [r0, r0 + nr), then the slice's selection partials.
+    // xs: LN_f(x) rounded to the operand type, fp32 [nb][D]; sl: the slice's logits [nb][BEAM_MAXR]
+    ps.wait();
+    float* sl = lds + MCAP * D;
+    head_phase<MCAP>(a, lds, r0, nr);
     __syncthreads();
     select_partials(a, sl, nb, r0, nr, T);
-    gs.wait();
-    if (blockIdx.x == 0) select_merge(a, nb, false, it, pos, G, lds);
-    gs.wait();
+    ps.arrive(G, true);
+    if (blockIdx.x == 0) { ps.wait(); select_merge(a, nb, false, it, pos, G, ntok0 + it, lds); }
+    ps.arrive(1, blockIdx.x == 0);
   }
 }
 

@@ -19,11 +19,10 @@ for _ in range(2):
     model.beam_search_native(emb, 3, 20, 0.5, -1)
 torch.cuda.synchronize()
 ws = keep['st'].select_ws
-st = ws[45000:45000+256].view(torch.int64).cpu().tolist()
-names = ["P1 start","P1 work end","P1 bar end","P2 work end","P2 bar end","P3 work end","P3 bar end","P4 work end","P4 bar end","P5 work end","P5 bar end","layers end","head+partials end","bar end","merge end","bar end"]
-for wg, off in (("WG0", 0), ("WG100", 64)):
-    v = st[off:off+16]
-    print(wg, "clock ticks (s_memtime, 100 MHz?)")
-    for i in range(1, 16):
-        print(f"  {names[i]:18s} +{v[i]-v[i-1]:8d}")
-    print("  total step", v[15]-v[0])
+st = ws[45000:45000+64].view(torch.int64).cpu().tolist()
+names = ["weights issued","wait done","A staged","sync","FMA done","reduce done","stores issued","arrive done (sync+atomic)"]
+for ph, off in (("P3 (A from 16-bit rows, K=768)", 0), ("P4 (LayerNorm, K=768, N=3072)", 16)):
+    v = st[off:off+8]
+    print(ph)
+    for i in range(1, 8):
+        print(f"   {names[i]:28s} +{v[i]-v[i-1]:7d} ticks")
