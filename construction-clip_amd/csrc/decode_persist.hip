@@ -171,7 +171,7 @@ __device__ __forceinline__ void attn_task(const BeamArgs& a, const bf16* q, long
 
 // ---- per-beam partials of one vocabulary slice (sl: [n_in][BEAM_MAXR] logits of rows r0..r0+nr) ----------------------------
 // wave w handles beams w, w+4: slice max and sum-exp of z = logit / T, and the slice's top-k by z (k = a.nb)
-__device__ __noinline__ void select_partials(const BeamArgs& a, const float* sl, int n_in, int r0, int nr, float inv_t_is_div) {
+__device__ __forceinline__ void select_partials(const BeamArgs& a, const float* sl, int n_in, int r0, int nr, float inv_t_is_div) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float T = inv_t_is_div;
   for (int m = wave; m < n_in; m += 4) {
@@ -207,7 +207,8 @@ __device__ __noinline__ void select_partials(const BeamArgs& a, const float* sl,
 }
 
 // ---- the selection proper, by workgroup 0 (256 threads); lds: 64 + 512 + 4096 + 2 * n_in*G*k floats -------------------------------
-__device__ __noinline__ void select_merge(const BeamArgs& a, int n_in, bool first, int it, int cur_pos, int G, int ntok, float* lds) {
+template <int MCAP>
+__device__ __forceinline__ void select_merge(const BeamArgs& a, int n_in, bool first, int it, int cur_pos, int G, int ntok, float* lds) {
   const int tid = threadIdx.x;
   const int nb = a.nb, k = a.nb;
   float* bM = lds;            // [8] global max per beam
@@ -274,10 +275,10 @@ __device__ __noinline__ void select_merge(const BeamArgs& a, int n_in, bool firs
   }
   __syncthreads();
   const int C = n_in * G * k;
-  for (int c0 = tid; c0 < C; c0 += 3072) {                          // candidates: twelve per thread in flight
-    float zz[12]; int tk[12];
+  for (int c0 = tid; c0 < C; c0 += 2304) {                          // candidates: nine per thread in flight
+    float zz[9]; int tk[9];
 #pragma unroll
-    for (int u = 0; u < 12; ++u) {
+    for (int u = 0; u < 9; ++u) {
       const int c = c0 + 256 * u < C ? c0 + 256 * u : C - 1;
       const int r = c % k, g = (c / k) % G, m = c / (k * G);
       const float* pp = a.part + ((long)g * 8 + m) * BEAM_PS;
@@ -285,7 +286,7 @@ __device__ __noinline__ void select_merge(const BeamArgs& a, int n_in, bool firs
       tk[u] = ld_coh<true>((const int*)pp + 3 + 2 * r);
     }
 #pragma unroll
-    for (int u = 0; u < 12; ++u) {
+    for (int u = 0; u < 9; ++u) {
       const int c = c0 + 256 * u;
       if (c >= C) continue;
       const int r = c % k, g = (c / k) % G, m = c / (k * G);
@@ -344,36 +345,46 @@ __device__ __noinline__ void select_merge(const BeamArgs& a, int n_in, bool firs
   // addresses), then the stores: issued phase by phase this was ~8 dependent memory round trips
   const int next_pos = first ? a.pos0 : cur_pos + 1;
   const bool has_next = next_pos < a.max_len;
-  int told[8], sold[8];
-  float e[8][4], pe[4];
+  int told[MCAP], sold[MCAP];
+  float e[MCAP][4], pe[4];
   {
     const int j = tid < ntok ? tid : 0;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) told[m] = a.tokens[(long)(m < n_in ? m : 0) * a.ld_tokens + j];
+    for (int m = 0; m < MCAP; ++m) told[m] = a.tokens[(long)(m < n_in ? m : 0) * a.ld_tokens + j];
     const int t = tid <= cur_pos ? tid : 0;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) sold[m] = ld_coh<true>(a.slot_of + (long)(t < 0 ? 0 : t) * 8 + m);
+    for (int m = 0; m < MCAP; ++m) sold[m] = ld_coh<true>(a.slot_of + (long)(t < 0 ? 0 : t) * 8 + m);
     const int np = has_next ? next_pos : 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int d = tid + 256 * u < a.D ? tid + 256 * u : 0;
       pe[u] = a.wpe32[(long)np * a.D + d];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) e[i][u] = a.wte32[(long)tok[i < nb ? i : 0] * a.D + d];
+      for (int i = 0; i < MCAP; ++i) e[i][u] = a.wte32[(long)tok[i < nb ? i : 0] * a.D + d];
     }
   }
   if (tid < ntok) {                                                 // tokens = cat(tokens[next_tokens_source], next_tokens)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (i < nb) a.tokens[(long)i * a.ld_tokens + tid] = told[src[i]];
+    for (int i = 0; i < MCAP; ++i) {
+      int v = told[0];
+#pragma unroll
+      for (int m = 1; m < MCAP; ++m) v = src[i] == m ? told[m] : v;          // (select chain: no dynamically indexed register array)
+      if (i < nb) a.tokens[(long)i * a.ld_tokens + tid] = v;
+    }
   }
   if (!first && tid <= cur_pos) {                                   // cache reorder = permute the slot table
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (i < nb) st_coh<true>(a.slot_of + (long)tid * 8 + i, sold[src[i]]);
+    for (int i = 0; i < MCAP; ++i) {
+      int v = sold[0];
+#pragma unroll
+      for (int m = 1; m < MCAP; ++m) v = src[i] == m ? sold[m] : v;
+      if (i < nb) st_coh<true>(a.slot_of + (long)tid * 8 + i, v);
+    }
   }
   if (has_next) {
     if (tid < nb) st_coh<true>(a.slot_of + (long)next_pos * 8 + tid, tid);        // the next step appends beam b's row to slot b
 #pragma unroll
-    for (int i = 0; i < 8; ++i)                                     // next input: wte[token] + wpe[position] (D <= 1024: 4 per thread)
+    for (int i = 0; i < MCAP; ++i)                                  // next input: wte[token] + wpe[position] (D <= 1024: 4 per thread)
 #pragma unroll
       for (int u = 0; u < 4; ++u) if (i < nb && tid + 256 * u < a.D) st_coh<true>(a.x + (long)i * a.D + tid + 256 * u, e[i][u] + pe[u]);
   }
@@ -390,7 +401,12 @@ __device__ __noinline__ void select_merge(const BeamArgs& a, int n_in, bool firs
 #pragma unroll
       for (int m = 0; m < 8; ++m) old[m] = ld_coh<true>(a.slot_of + (long)t * 8 + m);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) if (i < nb) st_coh<true>(a.slot_of + (long)t * 8 + i, old[src[i]]);
+      for (int i = 0; i < 8; ++i) {
+        int v = old[0];
+#pragma unroll
+        for (int m = 1; m < 8; ++m) v = src[i] == m ? old[m] : v;
+        if (i < nb) st_coh<true>(a.slot_of + (long)t * 8 + i, v);
+      }
     }
   }
   __syncthreads();
@@ -527,7 +543,7 @@ __global__ __launch_bounds__(256) void gpt2_beam_persist_kernel(const BeamArgs a
     __syncthreads();
     select_partials(a, lds, 1, r0, nr, T);
     ps.arrive(G, true);
-    if (blockIdx.x == 0) { ps.wait(); select_merge(a, 1, true, it, a.pos0 - 1, G, ntok0 + it, lds); }
+    if (blockIdx.x == 0) { ps.wait(); select_merge<MCAP>(a, 1, true, it, a.pos0 - 1, G, ntok0 + it, lds); }
     ps.arrive(1, blockIdx.x == 0);
     ++it;
   }
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(256) void gpt2_beam_persist_kernel(const BeamArgs a
     __syncthreads();
     select_partials(a, sl, nb, r0, nr, T);
     ps.arrive(G, true);
-    if (blockIdx.x == 0) { ps.wait(); select_merge(a, nb, false, it, pos, G, ntok0 + it, lds); }
+    if (blockIdx.x == 0) { ps.wait(); select_merge<MCAP>(a, nb, false, it, pos, G, ntok0 + it, lds); }
     ps.arrive(1, blockIdx.x == 0);
   }
 }

@@ -19,10 +19,10 @@ for _ in range(2):
     model.beam_search_native(emb, 3, 20, 0.5, -1)
 torch.cuda.synchronize()
 ws = keep['st'].select_ws
-st = ws[45000:45000+64].view(torch.int64).cpu().tolist()
-names = ["weights issued","wait done","A staged","sync","FMA done","reduce done","stores issued","arrive done (sync+atomic)"]
-for ph, off in (("P3 (A from 16-bit rows, K=768)", 0), ("P4 (LayerNorm, K=768, N=3072)", 16)):
-    v = st[off:off+8]
-    print(ph)
-    for i in range(1, 8):
-        print(f"   {names[i]:28s} +{v[i]-v[i-1]:7d} ticks")
+st = ws[45000:45000+256].view(torch.int64).cpu().tolist()
+for wg, off in (("WG0", 0), ("WG20", 64)):
+    v = st[off:off+64]
+    ev = sorted((t, i) for i, t in enumerate(v) if t)
+    print(wg)
+    for (t, i), (t0, i0) in zip(ev[1:], ev[:-1]):
+        print(f"   stamp {i0:2d} -> {i:2d}: {t - t0:8d} ticks")
