@@ -116,6 +116,17 @@ def generate2(model, tokenizer, tokens=None, prompt=None, embed=None, entry_coun
             step_in = model.gpt.transformer.wte(out_tokens)
         else:
             step_in = embed
+        if getattr(model, "beam_native_ok", None) is not None and model.beam_native_ok(1) and entry_length >= 1 and top_p > 0:
+            # The nucleus filter never removes the most probable token (`remove[..., 0] = 0`, test.py:499), so the arg-max of the
+            # filtered logits IS the arg-max of the logits: this loop is a greedy search = the persistent beam kernel with one
+            # beam, which stops on the stop token exactly as the loop's `break` does (the stop token is the last one kept).
+            prev = out_tokens
+            new_tokens, _, _ = model.beam_search_native(step_in, 1, entry_length, temperature, stop_token,
+                                                        prompt_tokens=prev if embed is None else None)
+            # (from a prompt the kernel's token row starts with the prompt; from `embed` the running token list is kept in front)
+            out_tokens = new_tokens if embed is None or prev is None else torch.cat((prev.to(new_tokens.device), new_tokens), dim=1)
+            generated_list.append(tokenizer.decode(list(out_tokens.squeeze(0).cpu().numpy())))
+            continue
         cache = None
         for _ in range(entry_length):
             logits, cache = _step_logits(model, step_in, cache)

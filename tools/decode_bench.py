@@ -41,3 +41,18 @@ for name, fn in (("kv-cached generate_beam", lambda: generate_beam(model, Tok(),
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     print(f"{name:26s}: {dt * 1e3:8.1f} ms per caption ({steps} steps x {beam} beams) = {steps / dt:7.1f} steps/s", flush=True)
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+# the decode steps alone: a 67-selection caption minus a 1-selection caption (prefill + first selection), per step
+t_full = timed(lambda: generate_beam(model, Tok(), beam_size=beam, embed=emb, entry_length=steps, stop_token=-1))
+t_one = timed(lambda: generate_beam(model, Tok(), beam_size=beam, embed=emb, entry_length=1, stop_token=-1))
+print(f"prefill + first selection  : {t_one * 1e3:8.2f} ms;  decode step (step + selection, {beam} beams): {(t_full - t_one) / (steps - 1) * 1e3:6.3f} ms", flush=True)
