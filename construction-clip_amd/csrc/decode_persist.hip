@@ -642,7 +642,12 @@ extern "C" int CCLIP_FN(cclip_gpt2_beam_search)(const cclip_beam_desc* d, hipStr
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CCLIP_ERR_LAUNCH;
     n_cu = prop.multiProcessorCount;
   }
-  int G = n_cu < 256 ? n_cu : 256;                              // one workgroup per CU: every workgroup is resident, the barrier can fill
+  // at most one workgroup per CU (every workgroup resident: the hand-overs can fill).  The projection phases have 24-96 column
+  // blocks, so more workgroups than that only add pollers at the step boundaries: 96, or as many as the vocabulary slices need
+  // (measured on GPT-2-small, V = 21128: 0.685 ms / step with 96 workgroups, 0.727 with 256)
+  int G = (s.vocab + 223) / 224; if (G < 96) G = 96;
+  if (G > 256) G = 256;
+  if (G > n_cu) G = n_cu;
   if (d->grid_cap > 0 && d->grid_cap < G) G = d->grid_cap;
   int R = (s.vocab + G - 1) / G; R = (R + 31) / 32 * 32;
   if (R > BEAM_MAXR) return CCLIP_ERR_ARG;                      // vocabulary too large for one slice per workgroup
