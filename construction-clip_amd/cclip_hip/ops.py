@@ -657,23 +657,12 @@ SCATTER_DETERMINISTIC = True     # False: the one-launch fp32-atomics kernel (su
 _SEG_CHUNK = 64
 
 
-def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None, seq_stride: Optional[int] = None,
-                      seq_off: int = 0, keep: Optional[torch.Tensor] = None) -> None:
-    """demb[text[r]] += dx[(r // L) * seq_stride + seq_off + r % L] for r < rows (the embedding-table gradient).
-    keep: optional bool [rows] - rows known to carry a zero gradient (text positions after EOT) can be dropped up front.
-
-    Deterministic by default: the row list is sorted by token id (stable) and every run of equal ids is summed in list order
-    by the wave that owns its embedding row, runs longer than 64 rows through ordered partials (csrc/embed.hip).  The sort /
-    run bookkeeping below is integer index math on a [rows] vector; every float is added by the HIP kernels."""
-    L = rows if L is None else L
-    seq_stride = L if seq_stride is None else seq_stride
-    if not SCATTER_DETERMINISTIC:
-        check(lib.cclip_embed_scatter_add(_p(text_i32), _p(dx), c_long(dx.stride(-2)), c_int(rows), c_int(demb.shape[1]),
-                                          c_int(demb.shape[0]), _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off),
-                                          _stream()), "cclip_embed_scatter_add")
-        return
+def embed_scatter_tables(text_i32, V: int, *, rows: int, keep: Optional[torch.Tensor] = None):
+    """Index tables of the deterministic embedding-gradient sum (see embed_scatter_add): the row list sorted by token id
+    (stable) and, per sorted position, the chunk / run bookkeeping csrc/embed.hip walks.  Integer math on a [rows] vector that
+    depends on the token ids only - a training step can build it while the forward pass runs (clip/model.py does, on a side
+    stream: ~25 small launches incl. a sort and three scans, 1.2 ms when issued in the backward pass)."""
     dev = text_i32.device
-    V, D = demb.shape
     tok = text_i32[:rows].clamp(0, V - 1)
     if keep is not None:                                  # dropped rows sort to the end under a sentinel id and form no chunk
         tok = torch.where(keep[:rows], tok, torch.full_like(tok, V))
@@ -699,10 +688,31 @@ def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None,
     total = cidx[-1:] + 1
     cidx_at_next = torch.where(nxt_run < n, cidx[nxt_run.clamp(max=n - 1).long()] + (~new_chunk[nxt_run.clamp(max=n - 1).long()]).to(torch.int32), total.expand(n))
     rlen = torch.where(new_run & valid, cidx_at_next - cidx, torch.zeros_like(pos)).to(torch.int32)
-    partial = torch.empty(n, D, device=dev, dtype=torch.float32)        # slot per chunk; only multi-chunk runs touch it
-    check(lib.cclip_embed_segsum(_p(order), _p(st.contiguous()), _p(cend.to(torch.int32).contiguous()), _p(cidx.contiguous()),
-                                 _p(rlen.contiguous()), c_int(n), _p(dx), c_long(dx.stride(-2)), c_int(D), _p(demb), c_int(L),
-                                 c_int(seq_stride), c_int(seq_off), _p(partial), _stream()), "cclip_embed_segsum")
+    return (order.contiguous(), st.contiguous(), cend.to(torch.int32).contiguous(), cidx.contiguous(), rlen.contiguous())
+
+
+def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None, seq_stride: Optional[int] = None,
+                      seq_off: int = 0, keep: Optional[torch.Tensor] = None, tables=None) -> None:
+    """demb[text[r]] += dx[(r // L) * seq_stride + seq_off + r % L] for r < rows (the embedding-table gradient).
+    keep: optional bool [rows] - rows known to carry a zero gradient (text positions after EOT) can be dropped up front.
+    tables: embed_scatter_tables(text_i32, V, rows=rows, keep=keep) built earlier (same text / keep).
+
+    Deterministic by default: the row list is sorted by token id (stable) and every run of equal ids is summed in list order
+    by the wave that owns its embedding row, runs longer than 64 rows through ordered partials (csrc/embed.hip).  The sort /
+    run bookkeeping is integer index math on a [rows] vector; every float is added by the HIP kernels."""
+    L = rows if L is None else L
+    seq_stride = L if seq_stride is None else seq_stride
+    if not SCATTER_DETERMINISTIC:
+        check(lib.cclip_embed_scatter_add(_p(text_i32), _p(dx), c_long(dx.stride(-2)), c_int(rows), c_int(demb.shape[1]),
+                                          c_int(demb.shape[0]), _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off),
+                                          _stream()), "cclip_embed_scatter_add")
+        return
+    V, D = demb.shape
+    order, st, cend, cidx, rlen = tables if tables is not None else embed_scatter_tables(text_i32, V, rows=rows, keep=keep)
+    n = rows
+    partial = torch.empty(n, D, device=text_i32.device, dtype=torch.float32)        # slot per chunk; only multi-chunk runs touch it
+    check(lib.cclip_embed_segsum(_p(order), _p(st), _p(cend), _p(cidx), _p(rlen), c_int(n), _p(dx), c_long(dx.stride(-2)), c_int(D),
+                                 _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off), _p(partial), _stream()), "cclip_embed_segsum")
 
 
 def caption_embed(prefix_proj, ids_i32, wte, wpe, x, *, B: int, P: int, Lt: int) -> None:

@@ -365,6 +365,22 @@ class CLIP(nn.Module):
         feat = torch.empty(B, geo.embed_dim, device=dev, dtype=torch.float32)
         ops.gemm_f32(pooled, p["text_projection"].data.t(), feat)
         ctx = dict(saved=saved, tok=tok, xo=xo, rows=rows, pooled=pooled, stp=stp, B=B, L=L) if train else None
+        if train and ops.SCATTER_DETERMINISTIC:
+            # The index tables of the deterministic embedding-gradient sum depend on the token ids only: built NOW on a helper
+            # stream (under the forward pass's GEMMs) instead of at the end of the backward pass, where their ~25 small
+            # launches were 1.2 ms of the step's critical path.
+            # positions after a row's EOT carry an exactly-zero gradient (causal tower, EOT pooling): dropped from the row list
+            cur = torch.cuda.current_stream()
+            aux = self._rt.get("aux_stream")
+            if aux is None:
+                aux = self._rt["aux_stream"] = torch.cuda.Stream(device=dev)
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (rows - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
+                tables = ops.embed_scatter_tables(tok.view(-1), p["token_embedding.weight"].shape[0], rows=M, keep=keep)
+                ev = torch.cuda.Event()
+                ev.record(aux)
+            ctx["scatter_tables"], ctx["scatter_ready"] = tables, ev
         return feat, ctx
 
     def _text_backward(self, c: dict, dfeat: torch.Tensor):
@@ -402,9 +418,16 @@ class CLIP(nn.Module):
                    accumulate=A("positional_embedding"))
         if not A("token_embedding.weight"):
             g["token_embedding.weight"].zero_()
-        # positions after a row's EOT carry an exactly-zero gradient (causal tower, EOT pooling): drop them from the row list
-        keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (c["rows"] - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
-        ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, keep=keep)
+        if c.get("scatter_tables") is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(c["scatter_ready"])
+            for t in c["scatter_tables"]:
+                t.record_stream(cur)               # allocated on the helper stream, consumed here
+            ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, tables=c["scatter_tables"])
+        else:
+            # positions after a row's EOT carry an exactly-zero gradient (causal tower, EOT pooling): drop them from the row list
+            keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (c["rows"] - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
+            ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, keep=keep)
         ar.scale_grads(self._rt["txt_names"], 1.0 / S)
         ar.publish_grads(self._rt["txt_names"])
 
