@@ -689,7 +689,19 @@ class ClipCaptionModel(nn.Module):
         ops.caption_embed(proj, ids, p["model.transformer.wte.weight"].data, p["model.transformer.wpe.weight"].data, x,
                           B=B, P=P, Lt=Lt)
         xo = self._hidden_forward(x, B, S, mask, saved)
-        return xo, dict(saved=saved, msave=msave, ids=ids, B=B, S=S, Lt=Lt, xo=xo)
+        ctx = dict(saved=saved, msave=msave, ids=ids, B=B, S=S, Lt=Lt, xo=xo)
+        if train and ops.SCATTER_DETERMINISTIC and dev.type == "cuda" and p["model.transformer.wte.weight"].requires_grad:
+            # index tables of the deterministic wte-gradient sum: token ids only, so they are built now on a helper stream, under
+            # the forward pass, instead of inside the backward pass (clip/model.py does the same for the text tower)
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_aux_stream", None) is None:
+                self._aux_stream = torch.cuda.Stream(device=dev)
+            self._aux_stream.wait_stream(cur)
+            with torch.cuda.stream(self._aux_stream):
+                ctx["scatter_tables"] = ops.embed_scatter_tables(ids.view(-1), p["model.transformer.wte.weight"].shape[0], rows=B * Lt)
+                ctx["scatter_ready"] = torch.cuda.Event()
+                ctx["scatter_ready"].record(self._aux_stream)
+        return xo, ctx
 
     # ---- public: reference call signature ----
     def forward(self, tokens: torch.Tensor, prefix: torch.Tensor, attribute: torch.Tensor,
@@ -761,7 +773,13 @@ class ClipCaptionModel(nn.Module):
             if not A(wpe):
                 g[wpe].zero_()
             ops.colsum(dx, g[wpe][:S].view(-1), sc.floats(ops.colsum_ws_floats(B, S * D)), R=B, C=S * D, ld=S * D, accumulate=True)
-            ops.embed_scatter_add(c["ids"].view(-1), dx, g[wte_name], rows=B * Lt, L=Lt, seq_stride=S, seq_off=P)
+            tables = c.get("scatter_tables")
+            if tables is not None:
+                cur = torch.cuda.current_stream()
+                cur.wait_event(c["scatter_ready"])
+                for t in tables:
+                    t.record_stream(cur)
+            ops.embed_scatter_add(c["ids"].view(-1), dx, g[wte_name], rows=B * Lt, L=Lt, seq_stride=S, seq_off=P, tables=tables)
         # mapper: d prefix_proj = dx[b, :P]  -> a [B, P*D] matrix with row stride S*D inside dx / dxb
         if self._mstack is not None:
             if p["clip_project.linear.weight"].requires_grad:
