@@ -89,6 +89,34 @@ for k in keys:
         changed[k] = (cur, best, base, best_t)
         base = min(best_t, timed())
     print(f"{k}: {cur} -> {best}   step {base:.3f} ms", flush=True)
+# weight-gradient keys (split candidates): the same descent over the (tile, split) pairs the isolated tuner chooses from
+from cclip_hip.stack import wgrad_candidates  # noqa: E402
+wkeys = [k for k in Logged.seen if k in logged and k.split("|")[12] == "-1"]
+print(f"{len(wkeys)} weight-gradient keys", flush=True)
+for k in wkeys:
+    f = k.split("|")
+    M, N, K = int(f[1]), int(f[2]), int(f[3])
+    cur = logged[k]
+    best, best_t = cur, base
+    for cand in wgrad_candidates(M, N, K):
+        if tuple(cand) == tuple(cur) or (int(f[13]) and cand[0] == 3):      # (the 256x256 tile has no fused bias gradient)
+            continue
+        logged[k] = tuple(cand)
+        try:
+            t = timed()
+        except Exception:
+            logged[k] = cur
+            torch.cuda.synchronize()
+            continue
+        if t < best_t - 0.12:
+            t2 = timed()
+            if t2 < best_t - 0.12:
+                best, best_t = tuple(cand), max(t, t2)
+    logged[k] = best
+    if best != cur:
+        changed[k] = (cur, best, base, best_t)
+        base = min(best_t, timed())
+    print(f"{k}: {cur} -> {best}   step {base:.3f} ms", flush=True)
 print("changed:", json.dumps({k: [list(v[0]), list(v[1]), round(v[2], 3), round(v[3], 3)] for k, v in changed.items()}, indent=1))
 print(f"final {min(timed(), timed()):.3f} ms")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
