@@ -17,6 +17,7 @@ MI355X-native counterpart.)
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
