@@ -157,22 +157,55 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const Fp8Args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   issue(0);
-  for (int kt = 0; kt < nkt; ++kt) {
+  // One 128-deep K-tile = 32 MFMAs (32 cycles each) per wave against 24 ds_read_b128 and 8 LDS-DMA instructions.  Round 2:
+  // the DMA group of tile kt+1 used to be issued back to back right after the barrier (~500 clocks of VMEM issue with the
+  // matrix pipe idle, the round-1 finding on the 16-bit kernels) and every m-tile's A fragment was read just before its
+  // MFMAs.  Now: B fragments + the first A fragment up front, the other fragment reads and the DMA instructions ride one by
+  // one between the MFMAs (sched_group_barrier pipeline; the steady state is one basic block).
+  auto k_tile = [&](int kt, auto dma_tag) {
+    constexpr bool DMA = decltype(dma_tag)::value;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + 1 < nkt) issue(kt + 1);
     const char* At = smem + (kt & 1) * STAGE_BYTES_ + a_off;
     const char* Bt = smem + (kt & 1) * STAGE_BYTES_ + NSA * TILE_BYTES + b_off;
-    v8i wf[4];
+    v8i wf[4], xf[MT];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) wf[nt] = frag_rows_fp8(Bt, b_row + 16 * nt, lane);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const v8i xf = frag_rows_fp8(At, a_row + 16 * mt, lane);
+    for (int mt = 0; mt < MT / 2; ++mt) xf[mt] = frag_rows_fp8(At, a_row + 16 * mt, lane);
+    // program order: first-half reads, DMA, second-half reads - an LDS read may not sink below the DMA (an LDS write to the
+    // compiler), so this is what lets the DMA group start after 6 MFMAs instead of after the last fragment read
+    if (DMA) issue(kt + 1);
+#pragma unroll
+    for (int mt = MT / 2; mt < MT; ++mt) xf[mt] = frag_rows_fp8(At, a_row + 16 * mt, lane);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], xf, acc[mt][nt], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);          // 4 B fragments + A fragment 0 (two b128 reads each)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {                                // A fragments 1..3 under MFMAs 0..5
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-  }
+    if (DMA) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                              // the 8 DMA instructions of tile kt+1 under MFMAs 6..13
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                                // A fragments 4..7
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int kt = 0;
+  for (; kt + 1 < nkt; ++kt) k_tile(kt, std::true_type{});
+  if (kt < nkt) k_tile(kt, std::false_type{});
   // ---- epilogue: lane holds, per (mt, h), columns n0..n0+7 of row m (as in gemm_bf16_impl.h) ----
   const int li = lane & 15, g = lane >> 4;
   float sbv[2][8], bsv[2][8];
