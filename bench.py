@@ -346,7 +346,7 @@ def main():
                     help="train mode: skip the extra encode_image / forward-only / fp16-operand legs timed after the headline steps")
     ap.add_argument("--model", default="ViT-B/32")
     ap.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default="bf16",
-                    help="MFMA operand type; fp8 = e4m3 qkv / fc projections of the image tower (inference modes only), bf16 elsewhere")
+                    help="MFMA operand type; fp8 = e4m3 projections of the image tower's blocks (inference modes only; CCLIP_FP8_WIDE=0: qkv / fc only), bf16 elsewhere")
     ap.add_argument("--tower-streams", type=int, default=int(os.environ.get("CCLIP_TOWER_STREAMS", "2")),
                     help="2 = run the image and text towers (forward and backward) on two HIP streams")
     args = ap.parse_args()
@@ -375,7 +375,7 @@ def main():
     model = clip.build_model(init_state_dict(geo, 567), cdt).to(dev)
     model.train()
     if args.dtype == "fp8":
-        model.eval().fp8_projections()
+        model.eval().fp8_projections(wide=os.environ.get("CCLIP_FP8_WIDE", "1") != "0")   # 0: qkv / fc only (the round-1 form)
     parallel.broadcast_parameters(model)
     opt = coptim.AdamW(model, lr=1e-5)                       # CLIP/train.py:143 (HF AdamW, lr 1e-5)
     sched = coptim.get_linear_schedule_with_warmup(opt, 5000, 1000 * 50)   # CLIP/train.py:145-147

@@ -485,21 +485,82 @@ def layernorm_fwd_fp8(x: torch.Tensor, gamma, beta, out8: torch.Tensor, scale: t
                                       _p(out8), c_long(out8.stride(-2)), _p(scale), _stream()), "cclip_layernorm_fwd_fp8")
 
 
-def gemm_fp8(A8, scale_a, B8, scale_b, out16, *, bias=None, act: int = ACT_NONE, M: Optional[int] = None) -> None:
-    """out16[m][n] = act(scale_a[m] * scale_b[n] * sum_k A8[m][k] B8[n][k] + bias[n]); A8 [M,K], B8 [N,K] uint8 e4m3."""
+def quantize_mx_fp8(x16: torch.Tensor, out8: torch.Tensor, block_scale: torch.Tensor, *, rows: Optional[int] = None) -> None:
+    """x16 [R, C] 16-bit (C % 32 == 0) -> out8 [R, C] uint8 (e4m3 bytes) + block_scale [ceil(C/128), R, 4] uint8 (E8M0): every
+    32 consecutive columns of a row share the power-of-two scale 2^(e - 127) (the block-scaled MFMA's operand format); the
+    scale of (row r, block b) is block_scale[b >> 2, r, b & 3] (K-tile major: what the consuming GEMM reads per K-tile is
+    contiguous)."""
+    _req16(x16, "x16")
+    assert out8.dtype == torch.uint8 and x16.dim() == 2 and out8.shape[1] == x16.shape[1] and x16.stride(1) == 1 and out8.stride(1) == 1
+    R, C = x16.shape
+    R = R if rows is None else rows
+    _req_mx(block_scale, R, C, "block_scale")
+    check(_fn("cclip_quantize_mx_fp8", x16)(_p(x16), c_long(x16.stride(0)), c_int(R), c_int(C), _p(out8), c_long(out8.stride(0)),
+                                           _p(block_scale), c_long(block_scale.stride(0)), _stream()), "cclip_quantize_mx_fp8")
+
+
+def _req_mx(t: torch.Tensor, rows: int, cols: int, name: str):
+    if not (t.dtype == torch.uint8 and t.is_cuda and t.dim() == 3 and t.shape[0] * 128 >= cols and t.shape[1] >= rows and t.shape[2] == 4
+            and t.stride(2) == 1 and t.stride(1) == 4):
+        raise TypeError(f"{name}: expected a cuda uint8 [>= {(cols + 127) // 128}, >= {rows}, 4] block-scale tensor, got {tuple(t.shape)} {t.dtype}")
+
+
+def mx_scale_buffer(rows: int, cols: int, device) -> torch.Tensor:
+    """Block-scale tensor for a [rows, cols] block-scaled e4m3 operand: uint8 [ceil(cols/128), rows, 4]."""
+    return torch.empty((cols + 127) // 128, rows, 4, device=device, dtype=torch.uint8)
+
+
+class Fp8GemmDesc(ctypes.Structure):
+    """include/cclip_hip.h: cclip_fp8_gemm_desc"""
+    _fields_ = [("A", c_void_p), ("lda", c_long), ("scale_a", c_void_p), ("block_scale_a", c_void_p), ("ld_block_scale_a", c_long),
+                ("B", c_void_p), ("ldb", c_long), ("scale_b", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("bias", c_void_p), ("act", c_int), ("out16", c_void_p), ("ldc", c_long),
+                ("out_fp8", c_void_p), ("ld_out_fp8", c_long), ("out_block_scale", c_void_p), ("ld_out_block_scale", c_long),
+                ("out_f32", c_void_p), ("residual", c_void_p), ("ldf", c_long)]
+
+
+def gemm_fp8(A8, scale_a, B8, scale_b, out16=None, *, bias=None, act: int = ACT_NONE, M: Optional[int] = None,
+             block_scale_a=None, out_mx=None, out_f32=None, residual=None, half=None) -> None:
+    """act(sa[m] * sb[n] * sum_k A8[m][k] B8[n][k] + bias[n]); A8 [M,K], B8 [N,K] uint8 e4m3, sb per output channel.
+    A's scale: scale_a [M] fp32 per row, or block_scale_a [K/128, M, 4] uint8 E8M0 per 32-deep k block (applied by the MFMA).
+    Output (exactly one): out16 (16-bit) | out_mx = (out8 [M,N] uint8, block_scale [N/128, M, 4] uint8): e4m3 + E8M0 per 32 columns,
+    the next GEMM's block-scaled A operand | out_f32 (+ residual, fp32, may alias): the residual stream.
+    `half`: torch.bfloat16 / torch.float16 picks the library twin when no 16-bit tensor is among the arguments."""
     assert A8.dtype == torch.uint8 and B8.dtype == torch.uint8 and A8.stride(1) == 1 and B8.stride(1) == 1
-    _req16(out16, "out16")
     Mx, K = A8.shape
     N = B8.shape[0]
     M = Mx if M is None else M
-    assert B8.shape[1] == K and out16.shape[1] == N and out16.shape[0] >= M
+    assert B8.shape[1] == K
+    d = Fp8GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.scale_b = A8.data_ptr(), A8.stride(0), B8.data_ptr(), B8.stride(0), scale_b.data_ptr()
+    d.M, d.N, d.K, d.act = M, N, K, act
+    d.bias = 0 if bias is None else bias.data_ptr()
+    if block_scale_a is not None:
+        _req_mx(block_scale_a, M, K, "block_scale_a")
+        d.block_scale_a, d.ld_block_scale_a = block_scale_a.data_ptr(), block_scale_a.stride(0)
+    else:
+        _req(scale_a, torch.float32, "scale_a")
+        d.scale_a = scale_a.data_ptr()
+    if out16 is not None:
+        _req16(out16, "out16")
+        assert out16.shape[1] == N and out16.shape[0] >= M
+        d.out16, d.ldc = out16.data_ptr(), out16.stride(0)
+    if out_mx is not None:
+        o8, omx = out_mx
+        assert o8.dtype == torch.uint8 and o8.shape[1] == N and o8.shape[0] >= M and o8.stride(1) == 1
+        _req_mx(omx, M, N, "out_mx[1]")
+        d.out_fp8, d.ld_out_fp8, d.out_block_scale, d.ld_out_block_scale = o8.data_ptr(), o8.stride(0), omx.data_ptr(), omx.stride(0)
+    if out_f32 is not None:
+        _req(out_f32, torch.float32, "out_f32"); _req(residual, torch.float32, "residual")
+        assert out_f32.shape[1] == N and out_f32.stride(0) == residual.stride(0)
+        d.out_f32, d.residual, d.ldf = out_f32.data_ptr(), residual.data_ptr(), out_f32.stride(0)
     ev = None
     if GEMM_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    check(_fn("cclip_gemm_fp8", out16)(_p(A8), c_long(A8.stride(0)), _p(scale_a), _p(B8), c_long(B8.stride(0)), _p(scale_b), c_int(M),
-                                      c_int(N), c_int(K), _p(bias), c_int(act), _p(out16), c_long(out16.stride(0)), _stream()),
-          "cclip_gemm_fp8")
+    f16 = (out16.dtype if out16 is not None else half) == torch.float16
+    fn = lib.cclip_gemm_fp8_ex_f16 if f16 else lib.cclip_gemm_fp8_ex
+    check(fn(ctypes.byref(d), _stream()), "cclip_gemm_fp8_ex")
     if ev is not None:
         ev[1].record()
         GEMM_EVENTS.append((ev[0], ev[1], 2.0 * M * N * K, (1, 1), (M, N, K)))

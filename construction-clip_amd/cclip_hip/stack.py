@@ -98,6 +98,9 @@ class BlockStack:
         # fp8 (e4m3) inference projections (BASELINE config 5): the LN-fed GEMMs (qkv, fc) take their A operand as e4m3
         # rows straight from a LayerNorm with fused quantisation, weights quantised per output channel once
         self.fp8 = False
+        # round 2: out-proj and c_proj too, their A operands block-scaled (one E8M0 exponent per 32 k: the attention output is
+        # quantised by one extra pass, the MLP hidden leaves the fc GEMM's epilogue as e4m3 + block scales directly)
+        self.fp8_wide = True
         self._fp8_weights = None
 
     def quantise_weights_fp8(self) -> None:
@@ -106,7 +109,7 @@ class BlockStack:
         out = []
         for w in self.blocks:
             ent = {}
-            for name in ("w_qkv", "w_fc"):
+            for name in ("w_qkv", "w_fc", "w_o", "w_proj"):
                 m = getattr(w, name)
                 q = torch.empty(m.shape, device=m.device, dtype=torch.uint8)
                 sc = torch.empty(m.shape[0], device=m.device, dtype=torch.float32)
@@ -172,6 +175,11 @@ class BlockStack:
                 if l == 0:
                     x8 = torch.empty(M, D, device=dev, dtype=torch.uint8)
                     sx = torch.empty(M, device=dev, dtype=torch.float32)
+                    wide = self.fp8_wide and D % 128 == 0 and Hd % 128 == 0 and geo.act in (ops.ACT_NONE, ops.ACT_QUICKGELU)
+                    if wide:
+                        xmx = ops.mx_scale_buffer(M, D, dev)                              # block scales of the attention output
+                        g8 = torch.empty(M, Hd, device=dev, dtype=torch.uint8)
+                        gmx = ops.mx_scale_buffer(M, Hd, dev)
                 wq8, swq = self._fp8_weights[l]["w_qkv"]
                 ops.layernorm_fwd_fp8(x_in, w.ln1_w, w.ln1_b, x8, sx, rows=M)
                 ops.gemm_fp8(x8, sx, wq8, swq, qkv, bias=w.b_qkv, M=M)
@@ -188,15 +196,27 @@ class BlockStack:
                 assert not geo.causal and key_keep is None
                 ops.attention_small_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H,
                                         head_dim=geo.head_dim, lse=lse_l)
-            ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in, out_f32=x_mid, M=M)
+            if f8 and wide:
+                wo8, swo = self._fp8_weights[l]["w_o"]
+                ops.quantize_mx_fp8(a, x8, xmx, rows=M)
+                ops.gemm_fp8(x8, None, wo8, swo, bias=w.b_o, M=M, block_scale_a=xmx, out_f32=x_mid, residual=x_in, half=self.dtype)
+            else:
+                ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in, out_f32=x_mid, M=M)
             if f8 and geo.act in (ops.ACT_NONE, ops.ACT_QUICKGELU):
                 wf8, swf = self._fp8_weights[l]["w_fc"]
                 ops.layernorm_fwd_fp8(x_mid, w.ln2_w, w.ln2_b, x8, sx, rows=M)
-                ops.gemm_fp8(x8, sx, wf8, swf, g, bias=w.b_fc, act=geo.act, M=M)
+                if wide:
+                    ops.gemm_fp8(x8, sx, wf8, swf, bias=w.b_fc, act=geo.act, M=M, out_mx=(g8, gmx), half=self.dtype)
+                else:
+                    ops.gemm_fp8(x8, sx, wf8, swf, g, bias=w.b_fc, act=geo.act, M=M)
             else:
                 ops.layernorm_fwd(x_mid, w.ln2_w, w.ln2_b, rows=M, out_bf16=xn2, mean=m2, rstd=r2)
                 ops.gemm_bf16(xn2, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, out_pre=h, M=M)
-            ops.gemm_bf16(g, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=x_mid, out_f32=x_out, M=M)
+            if f8 and wide:
+                wp8, swp = self._fp8_weights[l]["w_proj"]
+                ops.gemm_fp8(g8, None, wp8, swp, bias=w.b_proj, M=M, block_scale_a=gmx, out_f32=x_out, residual=x_mid, half=self.dtype)
+            else:
+                ops.gemm_bf16(g, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=x_mid, out_f32=x_out, M=M)
             x = x_out
         return x
 

@@ -213,21 +213,27 @@ class CLIP(nn.Module):
             txt_names=[n for n in ar.names if not n.startswith("visual.") and n != "logit_scale"],
         )
         self._rt["vis"].fp8, self._rt["txt"].fp8 = getattr(self, "_fp8_projections", (False, False))
+        self._rt["vis"].fp8_wide = self._rt["txt"].fp8_wide = getattr(self, "_fp8_wide", True)
         self._rt["vis"].grad_hook = self._rt["txt"].grad_hook = ar.notify_grads
         if use_wt:
             self._rt["vis"].refresh_transposed = self._rt["txt"].refresh_transposed = ar.refresh_transposed
 
-    def fp8_projections(self, enabled: bool = True, text: bool = False):
-        """INFERENCE ONLY: run the LayerNorm-fed projections (qkv, fc) of the image tower - and, with text=True, of the text
-        tower - with e4m3 operands on the block-scaled fp8 MFMA (per-token / per-output-channel scales; BASELINE.json
-        configs[4] is encode_image).  Weights are re-quantised from the current 16-bit shadows at this call; call again after
-        changing parameters.  No reference fp8 behaviour exists: accuracy is bounded by test against the fp32 oracle (image
-        features ~2.5e-2 relative, cosine > 0.999; the 12-layer causal text tower is ~7e-2 and therefore opt-in), not matched."""
+    def fp8_projections(self, enabled: bool = True, text: bool = False, wide: bool = True):
+        """INFERENCE ONLY: run the block projections of the image tower - and, with text=True, of the text tower - with e4m3
+        operands on the block-scaled fp8 MFMA (BASELINE.json configs[4] is encode_image).  The LayerNorm-fed projections
+        (qkv, fc) take per-token / per-output-channel scales; with wide=True (default; needs width and hidden % 128 == 0)
+        out-proj and c_proj run in e4m3 as well, their A operands quantised in 32-element blocks with E8M0 scales that the
+        MFMA applies itself (the MLP hidden leaves the fc GEMM's epilogue in that format, the attention output takes one
+        quantisation pass).  Weights are re-quantised from the current 16-bit shadows at this call; call again after changing
+        parameters.  No reference fp8 behaviour exists: accuracy is bounded by test against the fp32 oracle (image features
+        ~2.5e-2 relative, cosine > 0.999; the 12-layer causal text tower is ~7e-2 and therefore opt-in), not matched."""
         self._fp8_projections = (bool(enabled), bool(enabled and text))
+        self._fp8_wide = bool(wide)
         if self._arena is not None and self._rt is not None:
             self._arena.refresh_shadows()
             for k, on in zip(("vis", "txt"), self._fp8_projections):
                 self._rt[k].fp8 = on
+                self._rt[k].fp8_wide = self._fp8_wide
                 self._rt[k]._fp8_weights = None
         return self
 

@@ -277,6 +277,34 @@ int cclip_layernorm_fwd_fp8(const float* x, int64_t ldx, int32_t rows, int32_t D
 int cclip_gemm_fp8(const void* A8, int64_t lda, const float* scale_a, const void* B8, int64_t ldb, const float* scale_b,
                    int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, void* out_bf16, int64_t ldc,
                    hipStream_t stream);
+/* Round 2: block-scaled (MX) A operands, so that the projections whose input no single workgroup sees a whole row of
+ * (out-proj <- attention, c_proj <- the fc GEMM's epilogue) can run in e4m3 too.
+ * cclip_quantize_mx_fp8: x16 [rows, cols] (cols % 32 == 0) -> e4m3 [rows, cols] + one E8M0 byte per (row, 32 columns):
+ *   x ~= 2^(e - 127) * fp8 with e the smallest exponent that keeps the block's amax within +-448.
+ *   Block-scale layout (both functions): K-tile major [cols/128][rows][4] bytes - the scale of (row r, block b) is byte
+ *   (b >> 2) * ld + 4 r + (b & 3), ld >= 4 * rows = the byte distance between the planes of consecutive 128-column groups.
+ * cclip_gemm_fp8_ex: cclip_gemm_fp8 in descriptor form with
+ *   - block_scale_a != NULL: A carries E8M0 block scales (K % 128 == 0, layout above) applied by the MFMA itself
+ *     (v_mfma_scale_f32_16x16x128_f8f6f4 takes one scale byte per lane = per (row, 32-deep k block)); scale_a is not read;
+ *   - exactly one output: out16 (16-bit), out_fp8 + out_block_scale (e4m3 + E8M0 per 32 output columns, N % 64 == 0: the
+ *     block-scaled A operand of the NEXT GEMM written straight from the epilogue), or out_f32 = residual + result (fp32
+ *     residual stream, shared leading dimension ldf; may alias).
+ *   Kernel set: act NONE with any combination above except (block scales, fp8 out); act QUICKGELU with row-scaled A and
+ *   out16 or out_fp8; anything else returns status 1. */
+int cclip_quantize_mx_fp8(const void* x_bf16, int64_t ldx, int32_t rows, int32_t cols, void* out_fp8, int64_t ldo,
+                          void* block_scale, int64_t ld_block_scale, hipStream_t stream);
+typedef struct cclip_fp8_gemm_desc {
+  const void* A; int64_t lda; const float* scale_a;
+  const void* block_scale_a; int64_t ld_block_scale_a;
+  const void* B; int64_t ldb; const float* scale_b;
+  int32_t M, N, K;
+  const float* bias;
+  int32_t act;
+  void* out16; int64_t ldc;
+  void* out_fp8; int64_t ld_out_fp8; void* out_block_scale; int64_t ld_out_block_scale;
+  float* out_f32; const float* residual; int64_t ldf;
+} cclip_fp8_gemm_desc;
+int cclip_gemm_fp8_ex(const cclip_fp8_gemm_desc* d, hipStream_t stream);
 
 /* ---- native driver of one KV-cached GPT-2 decode step ------------------------------------------
  * One call = the whole per-token launch sequence (per layer: ln_1, qkv GEMM, cache append, decode attention,
@@ -368,6 +396,9 @@ int cclip_quantize_rows_fp8_f16(const void* x_f16, int64_t ldx, int32_t rows, in
 int cclip_gemm_fp8_f16(const void* A8, int64_t lda, const float* scale_a, const void* B8, int64_t ldb, const float* scale_b,
                        int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, void* out_f16, int64_t ldc,
                        hipStream_t stream);
+int cclip_quantize_mx_fp8_f16(const void* x_f16, int64_t ldx, int32_t rows, int32_t cols, void* out_fp8, int64_t ldo,
+                              void* block_scale, int64_t ld_block_scale, hipStream_t stream);
+int cclip_gemm_fp8_ex_f16(const cclip_fp8_gemm_desc* d, hipStream_t stream);
 int cclip_adamw_step_f16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int32_t step,
                          int32_t correct_bias, float grad_scale, int32_t mode, void* f16_shadow,

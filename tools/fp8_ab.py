@@ -63,3 +63,26 @@ for name, M, N, K, act in shapes:
     fl = 2.0 * M * N * K
     print(f"{name:9s} M={M} N={N} K={K}: A {a * 1e3:7.1f} us ({fl / a / 1e9:6.0f} TF) -> B {b * 1e3:7.1f} us ({fl / b / 1e9:6.0f} TF) "
           f"({(b / a - 1) * 100:+.1f}%)  bit-identical: {same}", flush=True)
+
+# ---- in-tree library only: what the block-scaled A operand and the fp32 residual epilogue cost on the out-proj / c_proj shapes
+print("in-tree library: row-scaled A, 16-bit out | block-scaled A, 16-bit out | block-scaled A, fp32 residual stream | bf16 GEMM + residual")
+for name, M, N, K in (("L14 out", ML, 1024, 1024), ("L14 proj", ML, 1024, 4096), ("B32 out", MB, 768, 768), ("B32 proj", MB, 768, 3072)):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.03).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    A8, sa = torch.empty(M, K, device="cuda", dtype=torch.uint8), torch.empty(M, device="cuda")
+    Am, ae = torch.empty(M, K, device="cuda", dtype=torch.uint8), ops.mx_scale_buffer(M, K, "cuda")
+    W8, sw = torch.empty(N, K, device="cuda", dtype=torch.uint8), torch.empty(N, device="cuda")
+    ops.quantize_rows_fp8(W, W8, sw); ops.quantize_rows_fp8(A, A8, sa); ops.quantize_mx_fp8(A, Am, ae)
+    o16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(M, N, device="cuda", generator=g)
+    fns = [lambda: ops.gemm_fp8(A8, sa, W8, sw, o16, bias=bias),
+           lambda: ops.gemm_fp8(Am, None, W8, sw, o16, bias=bias, block_scale_a=ae),
+           lambda: ops.gemm_fp8(Am, None, W8, sw, bias=bias, block_scale_a=ae, out_f32=x, residual=x, half=torch.bfloat16),
+           lambda: ops.gemm_bf16(A, W, bias=bias, residual=x, out_f32=x)]
+    ts = [[] for _ in fns]
+    for _ in range(4):
+        for i, f in enumerate(fns):
+            ts[i].append(timeit(f))
+    print(f"{name:9s} " + " | ".join(f"{min(t) * 1e3:7.1f} us" for t in ts) + f"   quantise (MX) pass {timeit(lambda: ops.quantize_mx_fp8(A, Am, ae)) * 1e3:6.1f} us", flush=True)
