@@ -49,35 +49,46 @@ __device__ __forceinline__ int fswz(int kr) { return ((kr & 3) << 2) | ((kr >> 2
 // PERM: LDS row position rp of a K-contiguous sub-tile holds tile row 64*(rp>>6) + nperm((rp>>4)&3, rp&15)
 // (free at staging time because the DMA source address is per lane), so fragment reads stay natural.
 // NINSTR: wave-instructions actually issued (default: whole sub-tiles); a 192-row A tile needs 24 of its 32
-template <int KC, int PERM, int NSUB, int NW, int NINSTR = NSUB * 16>
+// one of those wave-instructions (index idx of the tile).  ASM: issued through inline asm, i.e. invisible to the compiler's
+// waitcnt pass - see the K-strided K loop below for why.
+template <int KC, int PERM, bool ASM = false>
+__device__ __forceinline__ void stage_piece(const bf16* __restrict__ G, long ld, int R, int Kend, int r0, int k0,
+                                            char* lds_tile, int idx, int lane) {
+  const int sub = idx >> 4, rb = idx & 15;
+  const bf16* src;
+  if (KC) {
+    const int rp = rb * 8 + (lane >> 3);                  // LDS row position 0..127 inside the sub-tile
+    const int c = (lane & 7) ^ (rp & 7);                  // logical 16-B chunk held at this LDS slot
+    int r = rp;
+    if (PERM) r = (rp & 64) + nperm((rp >> 4) & 3, rp & 15);
+    int gr = r0 + sub * 128 + r; gr = gr < R ? gr : R - 1;   // clamp: rows past the edge are never stored
+    const int gk = k0 + c * 8;
+    src = G + (long)gr * ld + gk;
+    if (gk >= Kend) src = (const bf16*)g_zero16;
+  } else {
+    const int kr = rb * 4 + (lane >> 4);                  // k-row 0..63
+    const int c = (lane & 15) ^ fswz(kr);
+    const int rpad = ((R + 7) & ~7) - 8;                  // last 16-B chunk of the (8-padded) row
+    int gc = r0 + sub * 128 + c * 8; gc = gc <= rpad ? gc : rpad;
+    const int gk = k0 + kr;
+    src = G + (long)gk * ld + gc;
+    if (gk >= Kend) src = (const bf16*)g_zero16;          // ragged contraction edge contributes zeros
+  }
+  char* dst = lds_tile + sub * TILE_BYTES + rb * 1024;
+  if (ASM) {
+    const unsigned off = (unsigned)(size_t)LDS_PTR(dst);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(off), "v"(src) : "memory", "m0");
+  } else {
+    glds16(src, dst);
+  }
+}
+
+template <int KC, int PERM, int NSUB, int NW, int NINSTR = NSUB * 16, bool ASM = false>
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, long ld, int R, int Kend, int r0, int k0,
                                            char* lds_tile, int wave, int lane) {
   static_assert(NINSTR % NW == 0, "every wave issues the same number of DMA instructions (counted vmcnt waits)");
 #pragma unroll
-  for (int i = 0; i < NINSTR / NW; ++i) {
-    const int idx = wave + NW * i;
-    const int sub = idx >> 4, rb = idx & 15;
-    const bf16* src;
-    if (KC) {
-      const int rp = rb * 8 + (lane >> 3);                  // LDS row position 0..127 inside the sub-tile
-      const int c = (lane & 7) ^ (rp & 7);                  // logical 16-B chunk held at this LDS slot
-      int r = rp;
-      if (PERM) r = (rp & 64) + nperm((rp >> 4) & 3, rp & 15);
-      int gr = r0 + sub * 128 + r; gr = gr < R ? gr : R - 1;   // clamp: rows past the edge are never stored
-      const int gk = k0 + c * 8;
-      src = G + (long)gr * ld + gk;
-      if (gk >= Kend) src = (const bf16*)g_zero16;
-    } else {
-      const int kr = rb * 4 + (lane >> 4);                  // k-row 0..63
-      const int c = (lane & 15) ^ fswz(kr);
-      const int rpad = ((R + 7) & ~7) - 8;                  // last 16-B chunk of the (8-padded) row
-      int gc = r0 + sub * 128 + c * 8; gc = gc <= rpad ? gc : rpad;
-      const int gk = k0 + kr;
-      src = G + (long)gk * ld + gc;
-      if (gk >= Kend) src = (const bf16*)g_zero16;          // ragged contraction edge contributes zeros
-    }
-    glds16(src, lds_tile + sub * TILE_BYTES + rb * 1024);
-  }
+  for (int i = 0; i < NINSTR / NW; ++i) stage_piece<KC, PERM, ASM>(G, ld, R, Kend, r0, k0, lds_tile, wave + NW * i, lane);
 }
 
 // ---- fragment reads (lane l: index i = l&15 of the 16-wide tile, k-group g = l>>4: k = 32ks+8g+j) ----
@@ -244,12 +255,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     epi_loads<EB, HAS_AUX, !HAS_AUX, HAS_AUX>(p, bm0 + wm0, bn0 + wn0, 0, li, g, rres, raux);
   }
 
+  // A K-strided operand (the weight-gradient layout: both; Conv1D weights / dgrad without the transposed shadows: B) is read
+  // with ds_read_b64_tr_b16 intrinsics, and for those the compiler's waitcnt pass puts s_waitcnt vmcnt(0) in front of the
+  // first read after ANY LDS-DMA it knows to be in flight (found in round 2 by reading the loops' ISA: "s_waitcnt vmcnt(6);
+  // s_barrier; s_waitcnt vmcnt(0); ds_read..." - the 3-stage kernels drained their whole prefetch queue every K-tile; the
+  // 128x128 kernel, which issues its DMA right after the barrier, waited for the NEXT tile before multiplying this one).
+  // The plain ds_read_b128 of the K-contiguous layout do not get that wait.  So these layouts issue their DMA through inline
+  // asm (PIN): the compiler sees no LDS-DMA, the counted waits in front of the barriers are the only ones, and the DMA
+  // instructions are placed between k-step 1's MFMAs by hand (sched_barrier pins; sched_group_barrier cannot see inline asm).
+  constexpr bool PIN = !(A_KC && B_KC);
 #pragma unroll
   for (int s = 0; s < PD; ++s) {
     if (kt0 + s < kt1) {
       char* sb = smem + s * STAGE_BYTES_;
-      stage_tile<A_KC, 0, NSA, NW, AI>(p.A, p.lda, p.M, p.K, bm0, (kt0 + s) * BK, sb, wave, lane);
-      stage_tile<B_KC, 1, NSB, NW>(p.B, p.ldb, p.N, p.K, bn0, (kt0 + s) * BK, sb + NSA * TILE_BYTES, wave, lane);
+      stage_tile<A_KC, 0, NSA, NW, AI, PIN>(p.A, p.lda, p.M, p.K, bm0, (kt0 + s) * BK, sb, wave, lane);
+      stage_tile<B_KC, 1, NSB, NW, NSB * 16, PIN>(p.B, p.ldb, p.N, p.K, bn0, (kt0 + s) * BK, sb + NSA * TILE_BYTES, wave, lane);
     }
   }
   int cur = 0;                                                   // stage holding tile kt
@@ -276,14 +296,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
     // LDS read instructions) and -2..-7 % with 3 stages, but +5..10 % on 2-stage forward-layout kernels, whose DMA
     // then starts too late to land within one iteration: the 256x256 configuration deals it out between k-step 0's
     // FIRST MFMAs instead (ILV_EARLY, neutral), and the 128x128 one keeps the DMA ahead of the fragment reads.
-    constexpr bool ILV = STAGES >= 3 || (MT >= 8 && !(A_KC && B_KC)) || (!A_KC && !B_KC);
-    constexpr bool ILV_EARLY = !ILV && MT >= 6;
+    constexpr bool ILV = !PIN && (STAGES >= 3 || (MT >= 8 && !(A_KC && B_KC)) || (!A_KC && !B_KC));
+    constexpr bool ILV_EARLY = !PIN && !ILV && MT >= 6;
     // tile kt has landed for this wave once at most the younger stages' DMAs are outstanding; the barrier then
     // (a) publishes every wave's part of tile kt and (b) proves every wave is done reading stage cur-1
     if (PD >= 3 && wait_tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
     else if (PD >= 2 && wait_tiles >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (DMA && !ILV && !ILV_EARLY) {
+    if (DMA && !PIN && !ILV && !ILV_EARLY) {
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
       stage_tile<A_KC, 0, NSA, NW, AI>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave, lane);
@@ -313,6 +333,60 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
       wf[1][nt] = B_KC ? frag_rows(Bt, b_row + 16 * nt, 1, lane) : frag_cols<BPERM>(Bt, b_row, nt, 1, lane);
+    constexpr int RDP = (A_KC ? MT : 2 * MT) + (B_KC ? 4 : 8);    // LDS read instructions per k-step
+    if constexpr (PIN) {
+      // k-step 0's MFMAs with k-step 1's reads between them (scheduled), then k-step 1's MFMAs with one DMA instruction of tile
+      // kt+PD after every DSTEP-th of them (written out and pinned)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[0][nt], xf[0][mt], acc[mt][nt]);
+      if (CS == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accb[mt] = CCLIP_MFMA_16x16x32(ones8, xf[0][mt], accb[mt]);
+      }
+      if (CS == 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) accb[nt] = CCLIP_MFMA_16x16x32(wf[0][nt], ones8, accb[nt]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, RDP, 0);
+#pragma unroll
+      for (int i = 0; i < RDP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT) / RDP > 0 ? (4 * MT) / RDP : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT + 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
+      char* sb = smem + ns * STAGE_BYTES_;
+      constexpr int GA = AI / NW;                                   // this wave's DMA instructions of the A tile; the rest are B's
+      constexpr int DSTEP = (4 * MT) / G > 0 ? (4 * MT) / G : 1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          acc[mt][nt] = CCLIP_MFMA_16x16x32(wf[1][nt], xf[1][mt], acc[mt][nt]);
+          const int idx = 4 * mt + nt;
+          if (DMA && idx % DSTEP == DSTEP - 1 && idx / DSTEP < G) {
+            const int i = idx / DSTEP;
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < GA) stage_piece<A_KC, 0, true>(p.A, p.lda, p.M, p.K, bm0, (kt + PD) * BK, sb, wave + NW * i, lane);
+            else stage_piece<B_KC, 1, true>(p.B, p.ldb, p.N, p.K, bn0, (kt + PD) * BK, sb + NSA * TILE_BYTES, wave + NW * (i - GA), lane);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      if (CS == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accb[mt] = CCLIP_MFMA_16x16x32(ones8, xf[1][mt], accb[mt]);
+      }
+      if (CS == 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) accb[nt] = CCLIP_MFMA_16x16x32(wf[1][nt], ones8, accb[nt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur + 1 == STAGES ? 0 : cur + 1;
+      return;
+    }
     if (DMA && ILV) {     // after the fragment reads in program order (the DMA writes LDS: the reads may not sink below it)
       int ns = cur + PD; ns = ns >= STAGES ? ns - STAGES : ns;
       char* sb = smem + ns * STAGE_BYTES_;
