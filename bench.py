@@ -21,8 +21,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
   cpu_baseline - the CPU oracle (kind "port": the reference's `clip` package is absent) timed
                  on the host cores, SURVEY.md 8d's procedure (bs 64, 3 warm-up + 5 timed, median): the train step and,
                  beside it, the forward-only encode+logits figure.
-and, in the default (train, one GPU) run, three extra objects timed after the headline steps: `encode_image`
-(images/s + fraction of the bf16 MFMA peak - BASELINE.md's 40 % target), `forward_only`, `parity_mode` (the same step
+and, in the default (train, one GPU) run, four extra objects timed after the headline steps: `encode_image`
+(images/s + fraction of the bf16 MFMA peak - BASELINE.md's 40 % target), `encode_image_fp8` (the same with the block
+projections in e4m3: BASELINE configs[4]'s path on the headline model), `forward_only`, `parity_mode` (the same step
 with fp16 operands).  `roofline.traffic` / `mfma_busy` are REPLAYED from committed rocprofv3 --pmc summaries and only
 when those were taken on the same GEMM kernel sources (see attach_replayed_pmc).
 """
@@ -305,6 +306,16 @@ def extra_legs(model, image, text, geo, B, args):
     out["forward_only"] = dict(pairs_per_s=round(B / t, 1), ms=round(t * 1e3, 3),
                                frac_of_bf16_peak=round((img_fl + txt_fl) * B / t / PEAK_BF16, 4),
                                note="encode_image + encode_text + logits + loss, forward only, 20 iterations")
+    if args.dtype != "fp8":
+        # the same encode_image with the block projections in e4m3 (BASELINE configs[4]'s path on the headline model): inference
+        # only, accuracy bounded not matched (tests/test_fp8_gpu.py: image features ~3e-2 of the fp32 oracle)
+        model.fp8_projections(True)
+        t = _time_loop(enc_image, 3, 20)
+        model.fp8_projections(False)
+        out["encode_image_fp8"] = dict(images_per_s=round(B / t, 1), ms=round(t * 1e3, 3), frac_of_bf16_peak=round(img_fl * B / t / PEAK_BF16, 4),
+                                       frac_of_fp8_peak=round(img_fl * B / t / (2 * PEAK_BF16), 4),
+                                       note="encode_image with e4m3 qkv / out-proj / fc / c_proj (block-scaled fp8 MFMA), same model and batch, "
+                                            "20 iterations; an extra, not the headline precision")
     model.train()
     if args.dtype == "bf16":
         m16 = clip.build_model(init_state_dict(geo, 567), torch.float16).to(image.device).train()
