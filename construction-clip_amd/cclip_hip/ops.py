@@ -385,6 +385,7 @@ class AttnDesc(ctypes.Structure):
         ("dout", c_void_p), ("lddo", c_long),
         ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
         ("lddq", c_long), ("lddk", c_long), ("lddv", c_long),
+        ("o_fp8", c_void_p), ("ldo_fp8", c_long), ("o_block_scale", c_void_p), ("ld_o_block_scale", c_long),
     ]
 
 
@@ -403,9 +404,16 @@ def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale, head_dim=64):
     return d
 
 
-def attention_fwd(q, k, v, o, *, B: int, T: int, H: int, causal: bool = False, key_keep=None, lse=None, scale=None) -> None:
-    """q/k/v/o: bf16 2-D views [B*T, >= H*64] (any row stride, inner stride 1); head h at columns h*64.."""
+def attention_fwd(q, k, v, o, *, B: int, T: int, H: int, causal: bool = False, key_keep=None, lse=None, scale=None, out_mx=None) -> None:
+    """q/k/v/o: bf16 2-D views [B*T, >= H*64] (any row stride, inner stride 1); head h at columns h*64..
+    out_mx = (o8 [B*T, H*64] uint8, block_scale [H*64/128, B*T, 4] uint8): the output as e4m3 + E8M0 block scales (the out-proj's
+    block-scaled fp8 operand, see gemm_fp8) instead of 16-bit; `o` is then only the dtype witness and is not written."""
     d = _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale)
+    if out_mx is not None:
+        o8, omx = out_mx
+        assert o8.dtype == torch.uint8 and o8.stride(1) == 1 and o8.shape[0] >= B * T and o8.shape[1] >= H * 64 and H % 2 == 0
+        _req_mx(omx, B * T, H * 64, "out_mx[1]")
+        d.o_fp8, d.ldo_fp8, d.o_block_scale, d.ld_o_block_scale = o8.data_ptr(), o8.stride(0), omx.data_ptr(), omx.stride(0)
     check(_fn("cclip_attention_fwd", q, k, v, o)(ctypes.byref(d), _stream()), "cclip_attention_fwd")
 
 

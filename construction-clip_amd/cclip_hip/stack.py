@@ -190,15 +190,18 @@ class BlockStack:
                 kv_out[0][l, :B, :T].copy_(qkv[:M, D:2 * D].view(B, T, D))
                 kv_out[1][l, :B, :T].copy_(qkv[:M, 2 * D:3 * D].view(B, T, D))
             if geo.head_dim == 64:
+                a_mx = f8 and wide and H % 2 == 0      # the attention writes the out-proj's block-scaled e4m3 operand itself
                 ops.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H, causal=geo.causal,
-                                  key_keep=key_keep, lse=lse_l)
+                                  key_keep=key_keep, lse=lse_l, out_mx=(x8, xmx) if a_mx else None)
             else:
+                a_mx = False
                 assert not geo.causal and key_keep is None
                 ops.attention_small_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H,
                                         head_dim=geo.head_dim, lse=lse_l)
             if f8 and wide:
                 wo8, swo = self._fp8_weights[l]["w_o"]
-                ops.quantize_mx_fp8(a, x8, xmx, rows=M)
+                if not a_mx:
+                    ops.quantize_mx_fp8(a, x8, xmx, rows=M)
                 ops.gemm_fp8(x8, None, wo8, swo, bias=w.b_o, M=M, block_scale_a=xmx, out_f32=x_mid, residual=x_in, half=self.dtype)
             else:
                 ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in, out_f32=x_mid, M=M)

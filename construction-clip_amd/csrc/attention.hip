@@ -34,7 +34,45 @@ struct AttnArgs {
   // backward only
   const bf16* dout; long lddo;
   bf16* dq; bf16* dk; bf16* dv; long lddq, lddk, lddv;
+  // forward, fp8 inference path: o8 != null -> the output goes out as e4m3 + E8M0 block scales instead of 16-bit (o is not written)
+  unsigned char* o8; long ldo8; unsigned char* omx; long ldomx;
 };
+
+// Output of one query row of one head as the block-scaled A operand of the out-proj GEMM (gemm_bf16_fp8ops.hip: e4m3, one E8M0
+// exponent per 32 columns, scale layout [columns / 128][rows][4]): a head's 64 dims are two blocks - dims 0..31 sit in o[0], o[1]
+// of the four lanes (row, g = 0..3), dims 32..63 in o[2], o[3].  Every lane of the wave calls (cross-lane amax); `live` guards
+// the stores.
+__device__ __forceinline__ void attn_store_mx(const AttnArgs& a, long row, int h, int g, const f32x4 (&o)[4], float inv, bool live) {
+  float am[2] = {0.f, 0.f};
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) am[dt >> 1] = fmaxf(am[dt >> 1], fabsf(o[dt][j] * inv));
+  int e[2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    float m = fmaxf(am[hb], __shfl_xor(am[hb], 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const unsigned bits = __float_as_uint(m * (1.0f / 448.0f));          // (e8m0_of of gemm_bf16_fp8ops.hip)
+    int ee = (int)(bits >> 23) + ((bits & 0x7FFFFFu) ? 1 : 0);
+    ee = ee < 1 ? 1 : ee;
+    e[hb] = ee > 253 ? 253 : ee;
+  }
+  if (!live) return;
+  unsigned char* op = a.o8 + row * a.ldo8 + h * 64 + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const float sc = inv * __uint_as_float((unsigned)(254 - e[dt >> 1]) << 23);
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = fminf(fmaxf(o[dt][j] * sc, -448.f), 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+    *(int*)(op + 16 * dt) = w;
+  }
+  if (g == 0) *(unsigned short*)(a.omx + (long)(h >> 1) * a.ldomx + 4 * row + ((2 * h) & 3)) = (unsigned short)(e[0] | (e[1] << 8));
+}
 
 __device__ __forceinline__ int at_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -163,7 +201,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
       }
     }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    if (qi < T) {
+    if (a.o8) {
+      attn_store_mx(a, row0 + (qi < T ? qi : 0), h, g, o, inv, qi < T);
+    } else if (qi < T) {
       bf16* op = a.o + (row0 + qi) * a.ldo + h * 64 + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -452,7 +492,9 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const AttnArgs a, in
   }
 #pragma unroll
   for (int t = 0; t < ALQ; ++t) {
-    if (qi[t] < T) {
+    if (a.o8) {
+      attn_store_mx(a, row0 + (qi[t] < T ? qi[t] : 0), h, g, o[t], l[t] > 0.f ? 1.0f / l[t] : 0.f, qi[t] < T);
+    } else if (qi[t] < T) {
       const float inv = l[t] > 0.f ? 1.0f / l[t] : 0.f;
       bf16* op = a.o + (row0 + qi[t]) * a.ldo + h * 64 + 4 * g;
 #pragma unroll
@@ -686,7 +728,11 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const AttnArgs a,
 using namespace CCLIP_NS;
 
 static bool attn_args_ok(const cclip_attn_desc* d, bool bwd) {
-  if (!d || !d->q || !d->k || !d->v || !d->o) return false;
+  if (!d || !d->q || !d->k || !d->v) return false;
+  if (d->o_fp8) {      // fp8 output (forward only): e4m3 rows + block scales replace o
+    if (bwd || !d->o_block_scale || (d->ldo_fp8 & 3) || ((uintptr_t)d->o_fp8 & 3) || ((uintptr_t)d->o_block_scale & 1) ||
+        d->ld_o_block_scale < 4 * (int64_t)d->B * d->T) return false;
+  } else if (!d->o) return false;
   if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->T > 8192 || d->head_dim != 64) return false;
   if ((d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7)) return false;
   if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->o) & 15) return false;
@@ -707,6 +753,7 @@ static AttnArgs attn_pack(const cclip_attn_desc* d) {
   a.dout = (const bf16*)d->dout; a.lddo = d->lddo;
   a.dq = (bf16*)d->dq; a.dk = (bf16*)d->dk; a.dv = (bf16*)d->dv;
   a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
+  a.o8 = (unsigned char*)d->o_fp8; a.ldo8 = d->ldo_fp8; a.omx = (unsigned char*)d->o_block_scale; a.ldomx = d->ld_o_block_scale;
   return a;
 }
 

@@ -134,6 +134,10 @@ typedef struct cclip_attn_desc {
   const void* dout; int64_t lddo;
   void* dq; void* dk; void* dv;
   int64_t lddq, lddk, lddv;
+  /* cclip_attention_fwd only (round 2, fp8 inference path): o_fp8 != NULL -> the output rows are written as e4m3 [B*T, H*64]
+   * (row stride ldo_fp8) + E8M0 block scales in cclip_quantize_mx_fp8's layout (plane stride ld_o_block_scale >= 4*B*T) - the
+   * block-scaled A operand of the out-proj GEMM (cclip_gemm_fp8_ex), with no 16-bit round trip; o is then not written. */
+  void* o_fp8; int64_t ldo_fp8; void* o_block_scale; int64_t ld_o_block_scale;
 } cclip_attn_desc;
 int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream);

@@ -167,6 +167,30 @@ def test_gemm_fp8_block_scaled_output(M, N, K, act, dt):
     assert blk.max() < 0.08, blk.max().item()                                            # every block on its own scale
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,H,causal", [(3, 50, 12, False), (2, 77, 8, True), (2, 577, 16, False), (1, 257, 4, False)])
+def test_attention_block_scaled_output(B, T, H, causal, dt):
+    """attention forward writing the out-proj's block-scaled e4m3 operand directly (short and key-block-tiled kernels): the
+    dequantised bytes are the 16-bit path's output to fp8 precision, block by block, and the exponents are those of each
+    (row, 32-column block)'s amax."""
+    o = _ops()
+    D = H * 64
+    g = torch.Generator(device="cuda").manual_seed(B + T + H)
+    qkv = (torch.randn(B * T, 3 * D, device="cuda", generator=g) * torch.logspace(-1, 0.5, 3 * D, device="cuda")[None, :]).to(dt)
+    ref = torch.empty(B * T, D, device="cuda", dtype=dt)
+    o.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:], ref, B=B, T=T, H=H, causal=causal)
+    q8 = torch.full((B * T, D), 0x7F, device="cuda", dtype=torch.uint8)
+    e3 = o.mx_scale_buffer(B * T, D, "cuda").zero_()
+    o.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:], ref, B=B, T=T, H=H, causal=causal, out_mx=(q8, e3))
+    got = _dequant_mx(q8, e3)
+    assert torch.isfinite(got).all()
+    r = ref.float()
+    blk = (got - r).view(B * T, D // 32, 32).norm(dim=2) / r.view(B * T, D // 32, 32).norm(dim=2).clamp_min(1e-20)
+    assert blk.max() < 0.08, blk.max().item()
+    d = (_mx_rows(e3, B * T).int() - _mx_exponent(r.abs().view(B * T, D // 32, 32).amax(2))).abs()
+    assert d.max() <= 1 and (d != 0).float().mean() < 0.05, (d.max().item(), (d != 0).float().mean().item())   # (ref is 16-bit rounded)
+
+
 def rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
