@@ -32,5 +32,5 @@ table("Train step, ViT-B/32 bs 1024 bf16, single stream (10 steps under the prof
       "r02_train_single_kernel_stats.csv", "r02_train_bs1024_hbm_traffic_pmc.json", "r02_train_bs1024_mfma_busy_pmc.json", 10)
 table("BASELINE configs[3]: caption train step (MLP mapper + GPT-2-small, V = 21128, bs 256, S = 80), 8 steps under the profiler",
       "r02_caption_kernel_stats.csv", "r02_caption_bs256_hbm_traffic_pmc.json", "r02_caption_bs256_mfma_busy_pmc.json", 8)
-table("BASELINE configs[4]: ViT-L/14@336px encode_image, bs 256, e4m3 qkv / fc projections, 6 steps under the profiler",
+table("BASELINE configs[4]: ViT-L/14@336px encode_image, bs 256, all four block projections in e4m3 (qkv / fc row-scaled, out-proj / c_proj block-scaled), 6 steps under the profiler",
       "r02_l14_fp8_kernel_stats.csv", "r02_l14_336_fp8_hbm_traffic_pmc.json", "r02_l14_336_fp8_mfma_busy_pmc.json", 6)
