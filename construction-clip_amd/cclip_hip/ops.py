@@ -121,8 +121,41 @@ def kernel_source_hash() -> str:
     return _TUNE_STATE["source_hash"]
 
 
+_DERIVED = set()      # keys filled in by _nearest_tuned: used, never written to the persisted table
+
+
 def _key_str(key) -> str:
     return "|".join(str(int(k)) if isinstance(k, bool) else str(k) for k in key)
+
+
+def _nearest_tuned(key: str):
+    """A shape the table does not hold whose only difference from a tuned one is its TOKEN dimension (rows of a forward-layout
+    GEMM, the contraction length of a weight-gradient GEMM) (within 16x) - a last partial batch, a packed text batch whose row
+    count follows the captions' lengths - takes that entry's tile configuration instead of being timed in the middle of the
+    step: deterministic (no timing), no synchronisation.  A weight gradient's split-K count is scaled with the contraction
+    length (same K-tiles per split).  CCLIP_TUNE_EXACT=1 (tools/tune_gemm.sh) disables it: every shape is then timed."""
+    import math, os
+    if os.environ.get("CCLIP_TUNE_EXACT") == "1":
+        return None
+    f = key.split("|")
+    tok = 3 if (f[4] == "0" and f[5] == "0") else 1            # field of the token dimension: K for the (0,0) layout, else M
+    want = int(f[tok])
+    best, best_d = None, math.log(16.0)
+    for k, v in _TUNED.items():
+        g = k.split("|")
+        if len(g) != len(f) or any(a != b for i, (a, b) in enumerate(zip(f, g)) if i != tok):
+            continue
+        d = abs(math.log(int(g[tok]) / want))
+        if d < best_d:
+            best, best_d = (k, v), d
+    if best is None:
+        return None
+    (k, (cfg, sp)) = best
+    if cfg == 4 and tok == 1 and want % 256:
+        cfg = 3               # the persistent streaming configuration covers full 256-row tiles only
+    if tok == 3 and sp > 1:
+        sp = max(1, min(sp, round(sp * want / int(k.split("|")[3]))))
+    return (cfg, sp)
 
 
 def load_tuned_table(path=None, force: bool = False) -> int:
@@ -155,7 +188,7 @@ def save_tuned_table(path=None) -> str:
     path = path or env or default
     blob = {"kernel_source_hash": kernel_source_hash(),
             "note": "GEMM tile configuration per (dtype, M, N, K, layout, epilogue, split) key; written by cclip_hip.ops",
-            "table": {k: list(v) for k, v in sorted(_TUNED.items())}}
+            "table": {k: list(v) for k, v in sorted(_TUNED.items()) if k not in _DERIVED}}
     tmp = f"{path}.tmp{os.getpid()}"
     with open(tmp, "w") as f:
         json.dump(blob, f, indent=0, sort_keys=True)
@@ -318,6 +351,12 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
                         split_k if split_candidates is None else -1, colsum_out is not None, colsum_of_b))
         choice = _TUNED.get(key)
         if choice is None:
+            choice = _nearest_tuned(key)
+            if choice is not None:
+                _TUNED[key] = choice                           # (in memory only: a derived entry is never persisted)
+                _TUNE_STATE["derived"] = _TUNE_STATE.get("derived", 0) + 1
+                _DERIVED.add(key)
+        if choice is None:
             cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 7)]
             if split_candidates is None and split_k > 1:
                 d.split_ws = split_ws.data_ptr()
@@ -386,6 +425,7 @@ class AttnDesc(ctypes.Structure):
         ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
         ("lddq", c_long), ("lddk", c_long), ("lddv", c_long),
         ("o_fp8", c_void_p), ("ldo_fp8", c_long), ("o_block_scale", c_void_p), ("ld_o_block_scale", c_long),
+        ("cu_seqlens", c_void_p),
     ]
 
 
@@ -404,22 +444,33 @@ def _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale, head_dim=64):
     return d
 
 
-def attention_fwd(q, k, v, o, *, B: int, T: int, H: int, causal: bool = False, key_keep=None, lse=None, scale=None, out_mx=None) -> None:
+def _attn_cu(d, cu, B):
+    if cu is not None:
+        assert cu.dtype == torch.int32 and cu.is_cuda and cu.is_contiguous() and cu.numel() == B + 1
+        d.cu_seqlens = cu.data_ptr()
+
+
+def attention_fwd(q, k, v, o, *, B: int, T: int, H: int, causal: bool = False, key_keep=None, lse=None, scale=None, out_mx=None,
+                  cu=None) -> None:
     """q/k/v/o: bf16 2-D views [B*T, >= H*64] (any row stride, inner stride 1); head h at columns h*64..
     out_mx = (o8 [B*T, H*64] uint8, block_scale [H*64/128, B*T, 4] uint8): the output as e4m3 + E8M0 block scales (the out-proj's
-    block-scaled fp8 operand, see gemm_fp8) instead of 16-bit; `o` is then only the dtype witness and is not written."""
+    block-scaled fp8 operand, see gemm_fp8) instead of 16-bit; `o` is then only the dtype witness and is not written.
+    cu (int32 [B+1], T <= 128): packed batch - sequence b is rows [cu[b], cu[b+1]), T = the longest length."""
     d = _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale)
+    _attn_cu(d, cu, B)
     if out_mx is not None:
         o8, omx = out_mx
-        assert o8.dtype == torch.uint8 and o8.stride(1) == 1 and o8.shape[0] >= B * T and o8.shape[1] >= H * 64 and H % 2 == 0
-        _req_mx(omx, B * T, H * 64, "out_mx[1]")
+        R = o.shape[0] if cu is not None else B * T            # packed batch: the caller's row count
+        assert o8.dtype == torch.uint8 and o8.stride(1) == 1 and o8.shape[0] >= R and o8.shape[1] >= H * 64 and H % 2 == 0
+        _req_mx(omx, R, H * 64, "out_mx[1]")
         d.o_fp8, d.ldo_fp8, d.o_block_scale, d.ld_o_block_scale = o8.data_ptr(), o8.stride(0), omx.data_ptr(), omx.stride(0)
     check(_fn("cclip_attention_fwd", q, k, v, o)(ctypes.byref(d), _stream()), "cclip_attention_fwd")
 
 
 def attention_bwd(q, k, v, o, lse, dout, dq, dk, dv, *, B: int, T: int, H: int, causal: bool = False, key_keep=None,
-                  scale=None) -> None:
+                  scale=None, cu=None) -> None:
     d = _attn_desc(q, k, v, o, lse, B, T, H, causal, key_keep, scale)
+    _attn_cu(d, cu, B)
     d.dout, d.lddo = dout.data_ptr(), dout.stride(-2)
     d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     d.lddq, d.lddk, d.lddv = dq.stride(-2), dk.stride(-2), dv.stride(-2)

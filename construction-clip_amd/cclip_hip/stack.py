@@ -119,14 +119,15 @@ class BlockStack:
         self._fp8_weights = out
 
     # ------------------------------------------------------------------ forward
-    def alloc_saved(self, B: int, device, T: Optional[int] = None) -> dict:
+    def alloc_saved(self, B: int, device, T: Optional[int] = None, M: Optional[int] = None) -> dict:
         """Activation store for one training forward.  The caller writes the stack input (fp32 [B*T, D])
-        into saved["xs"][0, 0] and passes that view as `x`."""
+        into saved["xs"][0, 0] and passes that view as `x`.  M: row count of a PACKED batch (sequences of different lengths
+        back to back, forward(..., cu=...)); default B*T."""
         D, H = self.geo.width, self.geo.heads
         Hd = self.geo.hidden or 4 * D
         T = T or self.geo.tokens
-        M, L = B * T, len(self.blocks)
-        return dict(T=T,
+        M, L = (M or B * T), len(self.blocks)
+        return dict(T=T, M=M, cu=None,
             bf=torch.empty(L, M, 6 * D + 2 * Hd, device=device, dtype=self.dtype),   # xn1 | qkv | a | xn2 | h | g
             xs=torch.empty(L, 2, M, D, device=device, dtype=torch.float32),      # x_in, x_mid
             st=torch.empty(L, 4, M, device=device, dtype=torch.float32),         # mean1 rstd1 mean2 rstd2
@@ -134,7 +135,8 @@ class BlockStack:
             out=torch.empty(M, D, device=device, dtype=torch.float32), B=B, key_keep=None)
 
     def forward(self, x: torch.Tensor, B: int, *, saved: Optional[dict] = None,
-                key_keep: Optional[torch.Tensor] = None, T: Optional[int] = None, kv_out=None) -> torch.Tensor:
+                key_keep: Optional[torch.Tensor] = None, T: Optional[int] = None, kv_out=None,
+                cu: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: fp32 [B*T, D] residual stream entering block 0; returns the stream leaving the last block.
         saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0].
         kv_out = (kcache, vcache), each [L, B, Smax, D] 16-bit: every layer's keys / values of positions [0, T) are
@@ -143,15 +145,19 @@ class BlockStack:
         D, H = geo.width, geo.heads
         Hd = geo.hidden or 4 * D
         T = T or geo.tokens
-        M = B * T
+        # cu (int32 [B+1]): PACKED batch - sequence b is rows [cu[b], cu[b+1]) of x, T = the longest length; every row-wise
+        # kernel simply sees M = x.shape[0] rows, only the attention needs the row ranges
+        M = x.shape[0] if cu is not None else B * T
+        assert cu is None or (geo.head_dim == 64 and T <= 128 and kv_out is None)
         L = len(self.blocks)
         dev = x.device
         kc = geo.linear_layout
         train = saved is not None
         if train:
-            assert x.data_ptr() == saved["xs"][0, 0].data_ptr() and saved["T"] == T
+            assert x.data_ptr() == saved["xs"][0, 0].data_ptr() and saved["T"] == T and saved["M"] == M
             bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
             saved["key_keep"] = key_keep
+            saved["cu"] = cu
         else:
             bf = torch.empty(M, 6 * D + Hd, device=dev, dtype=self.dtype)  # xn | qkv | a | - | g  (reused per layer)
         for l, w in enumerate(self.blocks):
@@ -192,7 +198,7 @@ class BlockStack:
             if geo.head_dim == 64:
                 a_mx = f8 and wide and H % 2 == 0      # the attention writes the out-proj's block-scaled e4m3 operand itself
                 ops.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H, causal=geo.causal,
-                                  key_keep=key_keep, lse=lse_l, out_mx=(x8, xmx) if a_mx else None)
+                                  key_keep=key_keep, lse=lse_l, out_mx=(x8, xmx) if a_mx else None, cu=cu)
             else:
                 a_mx = False
                 assert not geo.causal and key_keep is None
@@ -283,7 +289,7 @@ class BlockStack:
         D, H = geo.width, geo.heads
         Hd = geo.hidden or 4 * D
         B, T = saved["B"], saved["T"]
-        M = B * T
+        M = saved.get("M") or B * T
         L = len(self.blocks)
         dev = dx.device
         kc = geo.linear_layout
@@ -370,7 +376,7 @@ class BlockStack:
             if geo.head_dim == 64:
                 ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
                                   dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
-                                  key_keep=saved["key_keep"])
+                                  key_keep=saved["key_keep"], cu=saved.get("cu"))
             else:
                 ops.attention_small_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
                                         dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, head_dim=geo.head_dim)

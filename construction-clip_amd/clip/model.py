@@ -218,6 +218,11 @@ class CLIP(nn.Module):
         if use_wt:
             self._rt["vis"].refresh_transposed = self._rt["txt"].refresh_transposed = ar.refresh_transposed
 
+    def _pack_text_rows(self) -> bool:
+        import os
+        v = getattr(self, "pack_text_rows", None)
+        return (os.environ.get("CCLIP_PACK_TEXT", "1") != "0") if v is None else bool(v)
+
     def fp8_projections(self, enabled: bool = True, text: bool = False, wide: bool = True):
         """INFERENCE ONLY: run the block projections of the image tower - and, with text=True, of the text tower - with e4m3
         operands on the block-scaled fp8 MFMA (BASELINE.json configs[4] is encode_image).  The LayerNorm-fed projections
@@ -359,19 +364,47 @@ class CLIP(nn.Module):
         M = B * L
         tok = text.detach()[:, :L].to(torch.int32).contiguous()
         p = ar.params
-        saved = st.alloc_saved(B, dev, T=L) if train else None
-        x = saved["xs"][0, 0] if train else torch.empty(M, D, device=dev, dtype=torch.float32)
-        ops.text_embed(tok.view(-1), p["token_embedding.weight"].data, p["positional_embedding"].data, x, rows=M, L=L)
-        xo = st.forward(x, B, saved=saved, T=L)
-        # EOT = largest id in the row (openai/CLIP: x[arange, text.argmax(-1)]); integer index math only
-        rows = (torch.arange(B, device=dev) * L + eot).to(torch.int32).contiguous()
+        # PACKED rows (round 2; CCLIP_PACK_TEXT=0 / model.pack_text_rows = False disables): caption b only needs positions
+        # 0..eot_b - the tower is causal and only the EOT row is pooled, so later rows influence neither the features nor any
+        # gradient (their upstream gradient is exactly zero).  The tower runs on the sum(eot_b + 1) live rows, sequences back
+        # to back (cu = their row ranges), instead of on B*77: the same features and gradients (the weight gradients' sums lose
+        # only exact-zero terms) at about half the rows for captions of uniformly distributed length.  Costs one device->host
+        # sync per call (the row count sizes every launch); the embedding stays dense - its live rows are gathered in,
+        # and their gradients scattered back, by two index copies.
+        rowmap = cu = None
+        if self._pack_text_rows() and B > 1 and not torch.cuda.is_current_stream_capturing():
+            live = torch.arange(L, device=dev)[None, :] <= eot[:, None]
+            rowmap = live.reshape(-1).nonzero().squeeze(1)                    # packed row -> dense row b*L + t (the sync)
+            Mp = int(rowmap.numel())
+            if Mp < M:
+                cu = torch.zeros(B + 1, device=dev, dtype=torch.int32)
+                cu[1:] = torch.cumsum(eot + 1, 0)
+            else:
+                rowmap = None
+        xd = torch.empty(M, D, device=dev, dtype=torch.float32) if (cu is not None or not train) else None
+        if cu is not None:
+            saved = st.alloc_saved(B, dev, T=L, M=Mp) if train else None
+            ops.text_embed(tok.view(-1), p["token_embedding.weight"].data, p["positional_embedding"].data, xd, rows=M, L=L)
+            x = saved["xs"][0, 0] if train else torch.empty(Mp, D, device=dev, dtype=torch.float32)
+            torch.index_select(xd, 0, rowmap, out=x)
+            xo = st.forward(x, B, saved=saved, T=L, cu=cu)
+            rows = (cu[1:] - 1).contiguous()                                  # each caption's EOT row = its last packed row
+        else:
+            saved = st.alloc_saved(B, dev, T=L) if train else None
+            x = saved["xs"][0, 0] if train else xd
+            ops.text_embed(tok.view(-1), p["token_embedding.weight"].data, p["positional_embedding"].data, x, rows=M, L=L)
+            xo = st.forward(x, B, saved=saved, T=L)
+            # EOT = largest id in the row (openai/CLIP: x[arange, text.argmax(-1)]); integer index math only
+            rows = (torch.arange(B, device=dev) * L + eot).to(torch.int32).contiguous()
+        rows_dense = (torch.arange(B, device=dev) * L + eot).to(torch.int32)
         pooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         stp = torch.empty(2, B, device=dev, dtype=torch.float32)
         ops.layernorm_fwd(xo, p["ln_final.weight"].data, p["ln_final.bias"].data, rows=B, row_index=rows, out_f32=pooled,
                           mean=stp[0], rstd=stp[1])
         feat = torch.empty(B, geo.embed_dim, device=dev, dtype=torch.float32)
         ops.gemm_f32(pooled, p["text_projection"].data.t(), feat)
-        ctx = dict(saved=saved, tok=tok, xo=xo, rows=rows, pooled=pooled, stp=stp, B=B, L=L) if train else None
+        ctx = dict(saved=saved, tok=tok, xo=xo, rows=rows, rows_dense=rows_dense, rowmap=rowmap if cu is not None else None,
+                   Mp=x.shape[0], pooled=pooled, stp=stp, B=B, L=L) if train else None
         if train and ops.SCATTER_DETERMINISTIC:
             # The index tables of the deterministic embedding-gradient sum depend on the token ids only: built NOW on a helper
             # stream (under the forward pass's GEMMs) instead of at the end of the backward pass, where their ~25 small
@@ -383,7 +416,7 @@ class CLIP(nn.Module):
                 aux = self._rt["aux_stream"] = torch.cuda.Stream(device=dev)
             aux.wait_stream(cur)
             with torch.cuda.stream(aux):
-                keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (rows - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
+                keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (rows_dense - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
                 tables = ops.embed_scatter_tables(tok.view(-1), p["token_embedding.weight"].shape[0], rows=M, keep=keep)
                 ev = torch.cuda.Event()
                 ev.record(aux)
@@ -409,8 +442,9 @@ class CLIP(nn.Module):
         ops.gemm_f32(c["pooled"].t(), dfeat.t(), g["text_projection"], beta=1.0 if A("text_projection") else 0.0)
         dpooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         ops.gemm_f32(dfeat, p["text_projection"].data, dpooled)
-        dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
-        dxb = torch.zeros(M, D, device=dev, dtype=self.compute_dtype)
+        Mp = c["Mp"]                                  # rows the tower ran on (= M unless the batch was packed)
+        dx = torch.zeros(Mp, D, device=dev, dtype=torch.float32)
+        dxb = torch.zeros(Mp, D, device=dev, dtype=self.compute_dtype)
         sc = st.scratch
         ops.layernorm_bwd(dpooled, c["xo"], p["ln_final.weight"].data, c["stp"][0], c["stp"][1], rows=B,
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["ln_final.weight"],
@@ -418,6 +452,9 @@ class CLIP(nn.Module):
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
         st.grad_hook_enabled = S == 1.0
         dxb = st.backward(dx, dxb, c["saved"], acc)
+        if c["rowmap"] is not None:                   # back to dense rows for the (dense) embedding gradients; dead rows stay zero
+            dxp, dx = dx, torch.zeros(M, D, device=dev, dtype=torch.float32)
+            dx.index_copy_(0, c["rowmap"], dxp)
         gpos = g["positional_embedding"]
         if L < geo.context_length and not A("positional_embedding"):
             gpos[L:].zero_()                      # trimmed positions received no gradient
@@ -433,7 +470,7 @@ class CLIP(nn.Module):
             ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, tables=c["scatter_tables"])
         else:
             # positions after a row's EOT carry an exactly-zero gradient (causal tower, EOT pooling): drop them from the row list
-            keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (c["rows"] - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
+            keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (c["rows_dense"] - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
             ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, keep=keep)
         ar.scale_grads(self._rt["txt_names"], 1.0 / S)
         ar.publish_grads(self._rt["txt_names"])

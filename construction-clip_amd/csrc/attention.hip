@@ -36,6 +36,9 @@ struct AttnArgs {
   bf16* dq; bf16* dk; bf16* dv; long lddq, lddk, lddv;
   // forward, fp8 inference path: o8 != null -> the output goes out as e4m3 + E8M0 block scales instead of 16-bit (o is not written)
   unsigned char* o8; long ldo8; unsigned char* omx; long ldomx;
+  // packed (variable-length) batches, T <= 128 kernels: sequence b occupies rows [cu[b], cu[b+1]) and T is the longest length
+  // (tile-count dispatch, lse row stride); null: row b*T + t
+  const int* cu;
 };
 
 // Output of one query row of one head as the block-scaled A operand of the out-proj GEMM (gemm_bf16_fp8ops.hip: e4m3, one E8M0
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int T = a.T;
-  const long row0 = (long)b * T;
+  const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;
+  const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;
   const int nqt = (T + 15) >> 4;
   bf16x8 qn0, qn1;                                         // this wave's first query tile rides along with K and V
   {
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
         *(bf16x4*)(op + 16 * dt) = ov;
       }
-      if (g == 0 && a.lse) a.lse[((long)b * a.H + h) * T + qi] = msafe + __logf(l);
+      if (g == 0 && a.lse) a.lse[((long)b * a.H + h) * a.T + qi] = msafe + __logf(l);
     }
   }
 }
@@ -232,8 +235,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-  const int T = a.T;
-  const long row0 = (long)b * T;
+  const int T = a.cu ? a.cu[b + 1] - a.cu[b] : a.T;
+  const long row0 = a.cu ? (long)a.cu[b] : (long)b * a.T;
   {
     uint4 rq[NKS], rk[NKS], rv[NKS], rdo[NKS], ro[NKS];    // TP32 * 8 chunks = 256 * NKS: NKS per thread and operand
     head_load<NKS>(a.q + h * 64, a.ldq, row0, T, rq, tid);
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
     head_load<NKS>(a.dout + h * 64, a.lddo, row0, T, rdo, tid);
     head_load<NKS>(a.o + h * 64, a.ldo, row0, T, ro, tid);
     float lse_r = 1e30f;                                   // rows >= T: P = exp(s - 1e30) = 0
-    if (tid < T) lse_r = a.lse[((long)b * a.H + h) * T + tid];
+    if (tid < T) lse_r = a.lse[((long)b * a.H + h) * a.T + tid];
     const float keep_r = (tid < T && (!a.keep || a.keep[row0 + tid] != 0.f)) ? 1.f : 0.f;
     // zero dS (tiles skipped by the causal structure are read as zeros) while the loads fly
     for (int i = tid; i < TP32 * DS_LD / 16; i += 256) *(uint4*)(dSs + i * 16) = make_uint4(0, 0, 0, 0);
@@ -731,9 +734,10 @@ static bool attn_args_ok(const cclip_attn_desc* d, bool bwd) {
   if (!d || !d->q || !d->k || !d->v) return false;
   if (d->o_fp8) {      // fp8 output (forward only): e4m3 rows + block scales replace o
     if (bwd || !d->o_block_scale || (d->ldo_fp8 & 3) || ((uintptr_t)d->o_fp8 & 3) || ((uintptr_t)d->o_block_scale & 1) ||
-        d->ld_o_block_scale < 4 * (int64_t)d->B * d->T) return false;
+        (!d->cu_seqlens && d->ld_o_block_scale < 4 * (int64_t)d->B * d->T)) return false;   // (packed batch: the caller's row count)
   } else if (!d->o) return false;
   if (d->B <= 0 || d->H <= 0 || d->T <= 0 || d->T > 8192 || d->head_dim != 64) return false;
+  if (d->cu_seqlens && d->T > 128) return false;            // packed batches: the single-workgroup kernels only
   if ((d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7)) return false;
   if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->o) & 15) return false;
   if (bwd) {
@@ -753,6 +757,7 @@ static AttnArgs attn_pack(const cclip_attn_desc* d) {
   a.dout = (const bf16*)d->dout; a.lddo = d->lddo;
   a.dq = (bf16*)d->dq; a.dk = (bf16*)d->dk; a.dv = (bf16*)d->dv;
   a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
+  a.cu = d->cu_seqlens;
   a.o8 = (unsigned char*)d->o_fp8; a.ldo8 = d->ldo_fp8; a.omx = (unsigned char*)d->o_block_scale; a.ldomx = d->ld_o_block_scale;
   return a;
 }

@@ -138,6 +138,11 @@ typedef struct cclip_attn_desc {
    * (row stride ldo_fp8) + E8M0 block scales in cclip_quantize_mx_fp8's layout (plane stride ld_o_block_scale >= 4*B*T) - the
    * block-scaled A operand of the out-proj GEMM (cclip_gemm_fp8_ex), with no 16-bit round trip; o is then not written. */
   void* o_fp8; int64_t ldo_fp8; void* o_block_scale; int64_t ld_o_block_scale;
+  /* packed (variable-length) batches (round 2; cclip_attention_fwd / _bwd, T <= 128): cu_seqlens != NULL (int32 [B+1], device) ->
+   * sequence b occupies rows [cu[b], cu[b+1]) of q/k/v/o/d* and of key_keep, T = the longest length (lse keeps row stride T).
+   * The text tower's captions end at their EOT token: rows after it never influence the pooled feature (causal attention), so
+   * the tower runs on sum(len) rows instead of B*77. */
+  const int32_t* cu_seqlens;
 } cclip_attn_desc;
 int cclip_attention_fwd(const cclip_attn_desc* d, hipStream_t stream);
 int cclip_attention_bwd(const cclip_attn_desc* d, hipStream_t stream);

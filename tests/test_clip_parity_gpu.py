@@ -412,6 +412,41 @@ def test_trim_text_padding_changes_nothing_but_the_row_count(dtype):
     assert torch.equal(outs[1][2]["positional_embedding"][8:], torch.zeros_like(outs[1][2]["positional_embedding"][8:]))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_packed_text_rows_equal_dense_rows(dtype):
+    """The text tower on PACKED rows (each caption's positions 0..EOT back to back; default) against the dense [B, 77] run
+    (model.pack_text_rows = False): bit-identical features (every live row sees the same keys in the same order; only rows that
+    influence nothing are gone), the same loss, gradients equal up to the weight gradients' summation partition; positions no
+    caption reaches get an exactly-zero positional gradient either way.  ViT-B/32 text geometry at B = 64 and the small fixture."""
+    import clip
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    for name, B in (("test-small", 6), ("ViT-B/32", 64)):
+        geo = MODELS[name]
+        img = synthetic_images(B, geo, 1).cuda()
+        txt = synthetic_text(B, geo, 2).cuda()              # one EOT per row at a random position, zeros after
+        lens = txt.argmax(-1) + 1
+        assert lens.min() < lens.max()
+        outs = []
+        for pack in (False, True):
+            model = clip.build_model(init_state_dict(geo, 7), dtype).cuda().train()
+            model.pack_text_rows = pack
+            with torch.no_grad():
+                ft = model.encode_text(txt)
+            li, lt = model(img, txt)
+            loss = _ce(li, lt)
+            loss.backward()
+            outs.append((ft, li.detach(), loss.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        assert torch.equal(outs[0][0], outs[1][0]), (name, (outs[0][0] - outs[1][0]).abs().max().item())
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][2].item() == outs[1][2].item()
+        assert set(outs[0][3]) == set(outs[1][3])
+        for n in outs[0][3]:
+            assert rel(outs[1][3][n], outs[0][3][n]) < 2e-3, (name, n, rel(outs[1][3][n], outs[0][3][n]))
+        top = int(lens.max().item())
+        for o in outs:
+            assert torch.equal(o[3]["positional_embedding"][top:], torch.zeros_like(o[3]["positional_embedding"][top:]))
+
+
 def test_empty_and_single_row_batches():
     """Edge cases of the reference's call sites: an empty image folder (CLIP/predict.py batches whatever it finds) gives
     empty [0, embed] features, and a batch of one matches row 0 of the same inputs encoded in a larger batch."""

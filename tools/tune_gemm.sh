@@ -6,6 +6,8 @@
 set -e
 mkdir -p gpurun_out
 export CCLIP_TUNE_FILE=$PWD/gpurun_out/gemm_tune.json
+export CCLIP_TUNE_EXACT=1      # time every shape these runs meet (no nearest-shape fallback)
+export CCLIP_PACK_TEXT=0       # the table holds the dense text shapes; packed batches take the nearest entry
 cp -f construction-clip_amd/cclip_hip/gemm_tune.json "$CCLIP_TUNE_FILE" 2>/dev/null || true
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/tune_train_bf16.log 2>&1
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --dtype fp16 > gpurun_out/tune_train_fp16.log 2>&1
