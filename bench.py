@@ -21,7 +21,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
   cpu_baseline - the CPU oracle (kind "port": the reference's `clip` package is absent) timed
                  on the host cores, SURVEY.md 8d's procedure (bs 64, 3 warm-up + 5 timed, median): the train step and,
                  beside it, the forward-only encode+logits figure.
-and, in the default (train, one GPU) run, four extra objects timed after the headline steps: `encode_image`
+The text tower runs on PACKED rows by default (each caption's positions 0..EOT; `config.text_rows`, `dense_text_rows` leg).
+and, in the default (train, one GPU) run, extra objects timed after the headline steps: `encode_image`
 (images/s + fraction of the bf16 MFMA peak - BASELINE.md's 40 % target), `encode_image_fp8` (the same with the block
 projections in e4m3: BASELINE configs[4]'s path on the headline model), `forward_only`, `parity_mode` (the same step
 with fp16 operands).  `roofline.traffic` / `mfma_busy` are REPLAYED from committed rocprofv3 --pmc summaries and only
@@ -317,6 +318,24 @@ def extra_legs(model, image, text, geo, B, args):
                                        note="encode_image with e4m3 qkv / out-proj / fc / c_proj (block-scaled fp8 MFMA), same model and batch, "
                                             "20 iterations; an extra, not the headline precision")
     model.train()
+    if model._pack_text_rows():
+        # the same train step with the text tower on all 77 positions of every caption (what the reference computes)
+        oo = coptim.AdamW(model, lr=1e-5)
+
+        def step_dense():
+            oo.zero_grad()
+            fi, ft = model.encode_image_text(image, text)
+            loss, stats = clip.contrastive_loss(fi, ft, model.logit_scale, None)
+            loss.backward()
+            oo.step()
+
+        model.pack_text_rows = False
+        t = _time_loop(step_dense, 2, 6)
+        model.pack_text_rows = None
+        out["dense_text_rows"] = dict(ms_per_step=round(t * 1e3, 3), pairs_per_s=round(B / t, 1),
+                                      note="the same train step with the text tower run on all 77 positions of every caption "
+                                           "(CCLIP_PACK_TEXT=0; identical features, gradients equal to summation order); 6 iterations")
+        del oo
     if args.dtype == "bf16":
         m16 = clip.build_model(init_state_dict(geo, 567), torch.float16).to(image.device).train()
         o16 = coptim.AdamW(m16, lr=1e-5)
@@ -489,10 +508,23 @@ def main():
                                     else "encode_image+encode_text+logits forward only") + f", {args.model}, bs={B}/GPU, "
                        f"{geo.image_resolution}x{geo.image_resolution} N(0,1) images + 77-token captions, seeded synthetic weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "mode": args.mode},
-            "step_mfu_bf16": round(step_flops * world / (dt / args.steps) / (PEAK_BF16 * world), 4),
             "loss": round(loss_val, 5),
             "roofline": roof,
         }
+        # whole-step MFU from the GEMM FLOPs the step EXECUTES (the roofline leg's launches): with the text tower on packed rows
+        # that is less than the dense-equivalent 3 x 14.78 GFLOP per pair, which is reported beside it and labelled as such
+        exe = roof["flops_per_launch"] * roof["launches_per_step"] if roof else None
+        out["step_mfu_bf16"] = round((exe if exe else step_flops) / (dt / args.steps) / PEAK_BF16, 4)
+        out["step_mfu_bf16_dense_equivalent"] = round(step_flops / (dt / args.steps) / PEAK_BF16, 4)
+        if args.mode != "image":
+            live = int((text.argmax(-1) + 1).sum().item())
+            packed = model._pack_text_rows()
+            out["config"]["text_rows"] = {
+                "context_length": geo.context_length, "rows_dense": B * geo.context_length, "rows_live": live, "packed": packed,
+                "note": "captions end at their EOT token (position uniform in [2, 76], SURVEY.md 8d); the causal text tower pools the EOT "
+                        "row, so later positions influence neither features nor gradients" + (
+                            " - it runs on the live rows only, sequences back to back (CCLIP_PACK_TEXT=0: all 77 positions)" if packed
+                            else " - run on all 77 positions (CCLIP_PACK_TEXT=0)")}
         log("roofline leg done")
         if extras is not None:
             out.update(extras)

@@ -10,6 +10,9 @@ export CCLIP_TUNE_EXACT=1      # time every shape these runs meet (no nearest-sh
 export CCLIP_PACK_TEXT=0       # the table holds the dense text shapes; packed batches take the nearest entry
 cp -f construction-clip_amd/cclip_hip/gemm_tune.json "$CCLIP_TUNE_FILE" 2>/dev/null || true
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/tune_train_bf16.log 2>&1
+# the packed text tower's shapes for the default synthetic batch (about half the dense rows): other packed batches take the nearest
+CCLIP_PACK_TEXT=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/tune_train_bf16_packed.log 2>&1
+CCLIP_PACK_TEXT=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --dtype fp16 > gpurun_out/tune_train_fp16_packed.log 2>&1
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --dtype fp16 > gpurun_out/tune_train_fp16.log 2>&1
 python bench.py --mode image --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/tune_image.log 2>&1
 python bench.py --mode fwd --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/tune_fwd.log 2>&1
