@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/prof_r2
 P=profiles
 what=${@:-train caption l14}
-stats() { cp "$(ls $O/$1/*/*kernel_stats.csv | head -1)" $P/$2; }
+stats() { cp "$(ls -t $O/$1/*/*kernel_stats.csv | head -1)" $P/$2; }      # newest (gpurun merges: older calls' files may linger locally)
 line() { grep '^{"metric"' $O/$1.log | tail -1 > $P/$2; }
 for w in $what; do
   case $w in

@@ -6,8 +6,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r2
 mkdir -p $O
 B="python3 $R/bench.py --no-cpu-baseline --no-extras"
-kt() { rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -- $2 > $O/$1.log 2>&1 || echo "FAILED $1"; }
-pmc() { rocprofv3 --pmc $3 --output-format csv -d $O/$1 -- $2 > $O/$1.log 2>&1 || echo "FAILED $1"; }
+# (gpurun MERGES gpurun_out/ back: drop an earlier call's files of the same pass first, the fold would mix them)
+kt() { rm -rf $O/$1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -- $2 > $O/$1.log 2>&1 || echo "FAILED $1"; }
+pmc() { rm -rf $O/$1; rocprofv3 --pmc $3 --output-format csv -d $O/$1 -- $2 > $O/$1.log 2>&1 || echo "FAILED $1"; }
 # PROF_ONLY=l14 (or train / caption) restricts the run to one workload
 if [ -z "$PROF_ONLY" ] || [ "$PROF_ONLY" = train ]; then
 # 1. the headline train step: default (two tower streams + wgrad side stream) and serialised on one stream
