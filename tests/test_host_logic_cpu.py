@@ -187,3 +187,34 @@ def test_gemm_tune_table_roundtrip_and_source_hash(tmp_path, monkeypatch):
     finally:
         ops._TUNED.clear()
         ops._TUNED.update(saved)
+
+
+def test_gemm_tile_lookup_takes_the_nearest_token_count(monkeypatch):
+    """A GEMM the table holds at another token count (a packed text batch, a last partial batch) takes that entry instead of being
+    timed inside the step: nearest in the token dimension (rows of a forward-layout GEMM, the contraction length of a weight
+    gradient, whose split-K count is scaled with it); other shapes, layouts or epilogues never match; the persistent streaming
+    configuration is only handed to full 256-row tiles; CCLIP_TUNE_EXACT=1 switches the fallback off; derived entries are not saved."""
+    from cclip_hip import ops
+    saved, saved_d = dict(ops._TUNED), set(ops._DERIVED)
+    try:
+        ops._TUNED.clear(); ops._DERIVED.clear()
+        fwd = "bfloat16|%d|1536|512|1|1|0|0|1|0|0|1|1|0|0"
+        wg = "bfloat16|1536|512|%d|0|0|0|1|0|0|0|0|-1|1|0"
+        ops._TUNED[fwd % 78848] = (7, 1)
+        ops._TUNED[fwd % 40311] = (3, 1)
+        ops._TUNED[wg % 78848] = (2, 10)
+        ops._TUNED["bfloat16|51200|768|768|1|1|0|1|0|0|1|1|1|0|0"] = (4, 1)
+        assert ops._nearest_tuned(fwd % 45000) == (3, 1)
+        assert ops._nearest_tuned(fwd % 70000) == (7, 1)
+        assert ops._nearest_tuned(wg % 39424) == (2, 5)                                   # same K-tiles per split
+        assert ops._nearest_tuned(wg % 8000) == (2, 1)
+        assert ops._nearest_tuned(wg % 4000) is None                                       # more than 16x away: tuned on its own
+        assert ops._nearest_tuned("bfloat16|45000|1536|512|1|0|0|0|1|0|0|1|1|0|0") is None    # another layout
+        assert ops._nearest_tuned("bfloat16|45000|1536|768|1|1|0|0|1|0|0|1|1|0|0") is None    # another K
+        assert ops._nearest_tuned("bfloat16|51201|768|768|1|1|0|1|0|0|1|1|1|0|0") == (3, 1)   # configuration 4 needs M % 256 == 0
+        assert ops._nearest_tuned("bfloat16|25600|768|768|1|1|0|1|0|0|1|1|1|0|0") == (4, 1)
+        monkeypatch.setenv("CCLIP_TUNE_EXACT", "1")
+        assert ops._nearest_tuned(fwd % 45000) is None
+    finally:
+        ops._TUNED.clear(); ops._TUNED.update(saved)
+        ops._DERIVED.clear(); ops._DERIVED.update(saved_d)
