@@ -538,12 +538,20 @@ class ClipCaptionModel(nn.Module):
         return out
 
     # ---- shared forward to the final hidden states ----
-    def _hidden_forward(self, x: torch.Tensor, B: int, S: int, mask: Optional[torch.Tensor], saved: Optional[dict]):
+    def _hidden_forward(self, x: torch.Tensor, B: int, S: int, mask: Optional[torch.Tensor], saved: Optional[dict],
+                        cu: Optional[torch.Tensor] = None, rowmap: Optional[torch.Tensor] = None):
         keep = None
         if mask is not None:
             keep = mask.detach().to(torch.float32).contiguous()
             assert keep.shape == (B, S), f"attention_mask {tuple(mask.shape)} vs sequence {(B, S)}"
-        return self._stack.forward(x, B, saved=saved, key_keep=keep, T=S)
+            if rowmap is not None:
+                keep = keep.view(-1)[rowmap].contiguous()              # packed rows: the mask entries of the live positions
+        return self._stack.forward(x, B, saved=saved, key_keep=keep, T=S, cu=cu)
+
+    def _pack_rows(self) -> bool:
+        import os
+        v = getattr(self, "pack_rows", None)
+        return (os.environ.get("CCLIP_PACK_TEXT", "1") != "0") if v is None else bool(v)
 
     def _lm_rows(self, xo: torch.Tensor, rows: torch.Tensor, train: bool):
         """ln_f on the selected rows + lm_head (tied wte): logits fp32 [len(rows), V]."""
@@ -673,7 +681,7 @@ class ClipCaptionModel(nn.Module):
         n_sel = state[3] if state[2] else entry_length
         return bs.tokens[:, :n_prompt + n_sel].long(), bs.seq_lengths, bs.scores
 
-    def _embed_and_run(self, tokens, prefix, attribute, mask, train: bool):
+    def _embed_and_run(self, tokens, prefix, attribute, mask, train: bool, pack: bool = False):
         self._ensure_runtime()
         ar = self._arena
         ar.refresh_shadows()
@@ -683,13 +691,42 @@ class ClipCaptionModel(nn.Module):
         Lt = ids.shape[1]
         S = P + Lt
         proj, msave = self._mapper_forward(prefix, train)                              # train.py:262
-        saved = self._stack.alloc_saved(B, dev, T=S) if train else None
-        x = saved["xs"][0, 0] if train else torch.empty(B * S, D, device=dev, dtype=torch.float32)
         p = ar.params
-        ops.caption_embed(proj, ids, p["model.transformer.wte.weight"].data, p["model.transformer.wpe.weight"].data, x,
-                          B=B, P=P, Lt=Lt)
-        xo = self._hidden_forward(x, B, S, mask, saved)
-        ctx = dict(saved=saved, msave=msave, ids=ids, B=B, S=S, Lt=Lt, xo=xo)
+        # PACKED rows (caption_loss only; CCLIP_PACK_TEXT=0 / model.pack_rows = False disables): GPT-2 is causal and the loss
+        # ignores targets equal to 0 (train.py:357), so of sequence b only positions 0 .. P+A+len_b-2 matter (len_b = the
+        # caption's length up to its last non-zero token): the row that predicts token j is position P+A-1+j, and later rows
+        # are neither targets nor keys of a needed row.  The stack runs on those rows, sequences back to back (cu); the
+        # embedding is formed densely and its live rows gathered in, the gradient rows scattered back (as the CLIP text tower).
+        rowmap = cu = lens = tsel = None
+        if pack and self._pack_rows() and B > 1 and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            Lc = tokens.shape[1]
+            lens = ((tokens != 0) * torch.arange(1, Lc + 1, device=dev)[None, :]).amax(dim=1)        # last non-zero index + 1
+            need = (S - Lc + lens - 1).clamp(min=1)
+            live = torch.arange(S, device=dev)[None, :] < need[:, None]
+            tlive = torch.arange(Lc, device=dev)[None, :] < lens[:, None]                         # targets that can be non-zero
+            nzi = torch.cat((live.reshape(-1), tlive.reshape(-1))).nonzero().squeeze(1)          # ONE sync for both row lists
+            k = int((nzi < B * S).sum().item())
+            rowmap, tsel = nzi[:k], nzi[k:] - B * S
+            if k < B * S:
+                cu = torch.zeros(B + 1, device=dev, dtype=torch.int32)
+                cu[1:] = torch.cumsum(need, 0)
+            else:
+                rowmap = tsel = lens = None
+        Mp = int(rowmap.numel()) if cu is not None else B * S
+        saved = self._stack.alloc_saved(B, dev, T=S, M=Mp) if train else None
+        if cu is not None:
+            xd = torch.empty(B * S, D, device=dev, dtype=torch.float32)
+            ops.caption_embed(proj, ids, p["model.transformer.wte.weight"].data, p["model.transformer.wpe.weight"].data, xd,
+                              B=B, P=P, Lt=Lt)
+            x = saved["xs"][0, 0] if train else torch.empty(Mp, D, device=dev, dtype=torch.float32)
+            torch.index_select(xd, 0, rowmap, out=x)
+        else:
+            x = saved["xs"][0, 0] if train else torch.empty(B * S, D, device=dev, dtype=torch.float32)
+            ops.caption_embed(proj, ids, p["model.transformer.wte.weight"].data, p["model.transformer.wpe.weight"].data, x,
+                              B=B, P=P, Lt=Lt)
+        xo = self._hidden_forward(x, B, S, mask, saved, cu=cu, rowmap=rowmap if cu is not None else None)
+        ctx = dict(saved=saved, msave=msave, ids=ids, B=B, S=S, Lt=Lt, xo=xo, cu=cu, rowmap=rowmap if cu is not None else None,
+                   tsel=tsel, Mp=Mp)
         if train and ops.SCATTER_DETERMINISTIC and dev.type == "cuda" and p["model.transformer.wte.weight"].requires_grad:
             # index tables of the deterministic wte-gradient sum: token ids only, so they are built now on a helper stream, under
             # the forward pass, instead of inside the backward pass (clip/model.py does the same for the text tower)
@@ -734,7 +771,7 @@ class ClipCaptionModel(nn.Module):
         p, g = ar.params, ar.g
         acc = ar.begin_backward()
         B, S, Lt, P, D = c["B"], c["S"], c["Lt"], self.prefix_length, self.model_embedding_size
-        M = B * S
+        M = c.get("Mp") or B * S                       # rows the stack ran on (packed: the live rows only)
         dev = dlog_b.device
         xf, st = lm
         R = rows.numel()
@@ -767,6 +804,12 @@ class ClipCaptionModel(nn.Module):
                           accumulate=False if frozen else A(lnf_w),
                           ws=None if frozen else sc.floats(ops.layernorm_bwd_ws_floats(R, D)))
         dxb = stack.backward(dx, dxb, c["saved"], acc)
+        if c.get("rowmap") is not None:                # back to dense [B*S, D] rows for the embedding / mapper gradients
+            dxp, dxbp = dx, dxb
+            dx = torch.zeros(B * S, D, device=dev, dtype=torch.float32)
+            dxb = torch.zeros(B * S, D, device=dev, dtype=self.compute_dtype)
+            dx.index_copy_(0, c["rowmap"], dxp)
+            dxb.index_copy_(0, c["rowmap"], dxbp)
         if not frozen:
             # x = [prefix_proj | wte[ids]] + wpe[s]
             wpe = "model.transformer.wpe.weight"
@@ -849,13 +892,20 @@ class _CaptionLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model: ClipCaptionModel, tokens, prefix, attribute, mask, *params):
         need_grad = any(ctx.needs_input_grad)
-        xo, c = model._embed_and_run(tokens, prefix, attribute, mask, need_grad)
+        xo, c = model._embed_and_run(tokens, prefix, attribute, mask, need_grad, pack=True)
         B, S, Lc = c["B"], c["S"], tokens.shape[1]
         dev = tokens.device
         first = S - Lc - 1                                                    # = P + A - 1 (train.py:356)
-        rows = (torch.arange(B, device=dev)[:, None] * S + first + torch.arange(Lc, device=dev)[None, :]).reshape(-1).to(torch.int32)
+        if c["cu"] is not None:
+            # packed: only the targets up to each caption's last non-zero token (the rest are ignored by the loss anyway)
+            tsel = c["tsel"]
+            b_of, j_of = tsel // Lc, tsel % Lc
+            rows = (c["cu"][:-1].long()[b_of] + first + j_of).to(torch.int32).contiguous()
+            labels = tokens.reshape(-1)[tsel].to(torch.int32).contiguous()
+        else:
+            rows = (torch.arange(B, device=dev)[:, None] * S + first + torch.arange(Lc, device=dev)[None, :]).reshape(-1).to(torch.int32)
+            labels = tokens.reshape(-1).to(torch.int32).contiguous()
         logits, lm = model._lm_rows(xo, rows, need_grad)
-        labels = tokens.reshape(-1).to(torch.int32).contiguous()
         kept = int((labels != 0).sum().item())                               # mean over non-ignored targets
         R = rows.numel()
         loss_rows = torch.empty(R, device=dev, dtype=torch.float32)

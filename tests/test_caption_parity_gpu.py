@@ -143,6 +143,33 @@ def test_caption_bs256_properties():
     assert worst[0] < 2e-2, worst
 
 
+def test_caption_loss_on_packed_rows_equals_dense_rows():
+    """caption_loss runs GPT-2 on each sequence's rows up to the one that predicts its last non-zero token (default) - against
+    the same call on all P + A + L rows (model.pack_rows = False): the same loss and gradients (only rows that are neither
+    targets nor keys of a needed row are gone; sums are partitioned differently), a key-padding mask is carried along, and a zero
+    token INSIDE a caption stays an ignored target without cutting the sequence."""
+    from clip_caption import ClipCaptionModel, GPT2_MODELS, init_caption_state_dict, synthetic_caption_batch
+    geo = GPT2_MODELS["ckiplab/gpt2-base-chinese"]
+    B, Lc = 24, 40
+    tokens, mask, prefix, attribute = [t.cuda() for t in synthetic_caption_batch(B, geo, Lc, 43)]
+    tokens[3, 2] = 0                                   # interior zero: ignored target, sequence continues
+    tokens[5, :] = 0                                   # an empty caption contributes nothing
+    mask = mask.clone(); mask[7, 3:9] = 0              # some masked keys inside the attribute block
+    outs = []
+    for pack in (False, True):
+        model = ClipCaptionModel(geo.prefix_length, prefix_size=geo.prefix_size, gpt2_type=geo)
+        model.load_state_dict(init_caption_state_dict(geo, 41))
+        model = model.cuda().train()
+        model.pack_rows = pack
+        loss = model.caption_loss(tokens, prefix, attribute, mask)
+        loss.backward()
+        outs.append((loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert abs(outs[0][0] - outs[1][0]) < 2e-6 * abs(outs[0][0]) + 1e-7, (outs[0][0], outs[1][0])
+    assert set(outs[0][1]) == set(outs[1][1])
+    worst = max((rel(outs[1][1][k], outs[0][1][k]), k) for k in outs[0][1])
+    assert worst[0] < 2e-3, worst
+
+
 def test_caption_reference_loop_with_torch_ce():
     """train.py:354-361 verbatim: outputs.logits slice -> nnf.cross_entropy(ignore_index=0) -> backward -> optimiser."""
     g, geo, model, tokens, mask, prefix, attribute = _setup()

@@ -17,6 +17,7 @@ python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --dtype fp16 
 python bench.py --mode image --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/tune_image.log 2>&1
 python bench.py --mode fwd --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/tune_fwd.log 2>&1
 python bench.py --mode caption --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/tune_caption.log 2>&1
+CCLIP_PACK_TEXT=1 python bench.py --mode caption --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/tune_caption_packed.log 2>&1
 python bench.py --mode image --model ViT-L/14@336px --batch 256 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/tune_l14.log 2>&1
 python - <<'PY'
 import json, os
