@@ -238,8 +238,15 @@ def caption_main(args, rank, world, dev, B, cdt):
                "config": {"workload": f"CLIP_prefix_caption/train.py step (fwd+bwd+AdamW), MLP mapper 512->7680->15360 + GPT-2-small "
                           f"V={geo.vocab_size}, bs={B}/GPU, prefix 20 + attribute 20 + {Lc} caption tokens (S={S}), seeded synthetic weights",
                           "global_batch": B * world, "parallelism": f"dp{world}", "mode": "caption"},
-               "step_mfu_bf16": round(3 * CAPTION_FWD_FLOPS * B * world / (dt / args.steps) / (PEAK_BF16 * world), 4),
+               "step_mfu_bf16_dense_equivalent": round(3 * CAPTION_FWD_FLOPS * B * world / (dt / args.steps) / (PEAK_BF16 * world), 4),
                "loss": round(float(loss.item()), 5), "roofline": gemm_roofline(ev, nprof), "cpu_baseline": None}
+        roof = out["roofline"]
+        out["step_mfu_bf16"] = round(roof["flops_per_launch"] * roof["launches_per_step"] / (dt / args.steps) / PEAK_BF16, 4)   # executed GEMM FLOPs
+        lens = ((tokens != 0) * torch.arange(1, Lc + 1, device=dev)[None, :]).amax(dim=1)
+        out["config"]["rows"] = {"rows_dense": B * S, "rows_live": int((S - Lc + lens - 1).clamp(min=1).sum().item()), "packed": model._pack_rows(),
+                                 "note": "GPT-2 is causal and the loss ignores zero targets (train.py:357): of a sequence only the rows up to the one "
+                                         "that predicts its last non-zero token matter; caption_loss runs the stack on those rows, sequences back "
+                                         "to back (CCLIP_PACK_TEXT=0: all P + A + L rows)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = caption_cpu_baseline(geo, Lc)
         print(json.dumps(out))
