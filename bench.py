@@ -231,7 +231,7 @@ def caption_main(args, rank, world, dev, B, cdt):
     if rank == 0:
         ev, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
         S = geo.prefix_length + geo.attribute_length + Lc
-        out = {"metric": "caption samples/sec (ClipCaptionModel train step: MLP mapper + GPT-2-small, bs=256)",
+        out = {"metric": f"caption samples/sec (ClipCaptionModel train step: MLP mapper + GPT-2-small, bs={B})",
                "value": round(B * world * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
