@@ -447,6 +447,20 @@ def test_packed_text_rows_equal_dense_rows(dtype):
             assert torch.equal(o[3]["positional_embedding"][top:], torch.zeros_like(o[3]["positional_embedding"][top:]))
 
 
+def test_image_lanes_are_bit_identical_to_the_whole_batch(monkeypatch):
+    """Inference on a large batch runs as two half batches on two HIP streams (clip/model.py:_image_forward_lanes): the same
+    features bit for bit as the whole batch on one stream, for an odd batch size too (encode_image_text keeps the image batch whole:
+    the text tower is its partner there)."""
+    model, img, txt = _b32_batch(701)
+    model.eval()
+    with torch.no_grad():
+        lanes = model.encode_image(img)
+        both = model.encode_image_text(img, txt)[0]
+        monkeypatch.setenv("CCLIP_IMAGE_LANES", "1")
+        whole = model.encode_image(img)
+    assert torch.equal(lanes, whole) and torch.equal(both, whole)
+
+
 def test_empty_and_single_row_batches():
     """Edge cases of the reference's call sites: an empty image folder (CLIP/predict.py batches whatever it finds) gives
     empty [0, embed] features, and a batch of one matches row 0 of the same inputs encoded in a larger batch."""
