@@ -136,7 +136,7 @@ class BlockStack:
 
     def forward(self, x: torch.Tensor, B: int, *, saved: Optional[dict] = None,
                 key_keep: Optional[torch.Tensor] = None, T: Optional[int] = None, kv_out=None,
-                cu: Optional[torch.Tensor] = None) -> torch.Tensor:
+                cu: Optional[torch.Tensor] = None, tail_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: fp32 [B*T, D] residual stream entering block 0; returns the stream leaving the last block.
         saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0].
         kv_out = (kcache, vcache), each [L, B, Smax, D] 16-bit: every layer's keys / values of positions [0, T) are
@@ -145,6 +145,10 @@ class BlockStack:
         D, H = geo.width, geo.heads
         Hd = geo.hidden or 4 * D
         T = T or geo.tokens
+        # tail_rows (int64 [R]): the caller only reads these rows of the stack's output (CLIP pools ONE token per sequence: the
+        # class token / the EOT token).  The last block's attention still needs every token's keys and values, but its out-proj,
+        # LayerNorm, fc and c_proj - 3/4 of a block's FLOPs - are then row-local work for R rows instead of M: they run on a
+        # compact [R, D] copy and the compact stream [R, D] is RETURNED instead of [M, D] (backward takes the compact gradient).
         # cu (int32 [B+1]): PACKED batch - sequence b is rows [cu[b], cu[b+1]) of x, T = the longest length; every row-wise
         # kernel simply sees M = x.shape[0] rows, only the attention needs the row ranges
         M = x.shape[0] if cu is not None else B * T
@@ -158,6 +162,7 @@ class BlockStack:
             bf, xs, st, lse = saved["bf"], saved["xs"], saved["st"], saved["lse"]
             saved["key_keep"] = key_keep
             saved["cu"] = cu
+            saved["tail"] = None
         else:
             bf = torch.empty(M, 6 * D + Hd, device=dev, dtype=self.dtype)  # xn | qkv | a | - | g  (reused per layer)
         for l, w in enumerate(self.blocks):
@@ -196,7 +201,7 @@ class BlockStack:
                 kv_out[0][l, :B, :T].copy_(qkv[:M, D:2 * D].view(B, T, D))
                 kv_out[1][l, :B, :T].copy_(qkv[:M, 2 * D:3 * D].view(B, T, D))
             if geo.head_dim == 64:
-                a_mx = f8 and wide and H % 2 == 0      # the attention writes the out-proj's block-scaled e4m3 operand itself
+                a_mx = f8 and wide and H % 2 == 0 and not (tail_rows is not None and l == L - 1)   # the attention writes the out-proj's block-scaled e4m3 operand itself
                 ops.attention_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H, causal=geo.causal,
                                   key_keep=key_keep, lse=lse_l, out_mx=(x8, xmx) if a_mx else None, cu=cu)
             else:
@@ -204,6 +209,22 @@ class BlockStack:
                 assert not geo.causal and key_keep is None
                 ops.attention_small_fwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, B=B, T=T, H=H,
                                         head_dim=geo.head_dim, lse=lse_l)
+            if tail_rows is not None and l == L - 1:
+                R = tail_rows.numel()
+                assert not a_mx
+                a_c = a.index_select(0, tail_rows)
+                xmid_c = torch.empty(R, D, device=dev, dtype=torch.float32)
+                ops.gemm_bf16(a_c, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in.index_select(0, tail_rows), out_f32=xmid_c, M=R)
+                tb = torch.empty(R, D + 2 * Hd, device=dev, dtype=self.dtype)            # xn2 | h | g of the kept rows
+                xn2_c, h_c, g_c = tb[:, 0:D], tb[:, D:D + Hd], tb[:, D + Hd:D + 2 * Hd]
+                st_c = torch.empty(2, R, device=dev, dtype=torch.float32)
+                ops.layernorm_fwd(xmid_c, w.ln2_w, w.ln2_b, rows=R, out_bf16=xn2_c, mean=st_c[0], rstd=st_c[1])
+                ops.gemm_bf16(xn2_c, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g_c, out_pre=h_c if train else None, M=R)
+                xout_c = torch.empty(R, D, device=dev, dtype=torch.float32)
+                ops.gemm_bf16(g_c, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=xmid_c, out_f32=xout_c, M=R)
+                if train:
+                    saved["tail"] = dict(rows=tail_rows, a=a_c, xmid=xmid_c, xn2=xn2_c, h=h_c, g=g_c, st=st_c)
+                return xout_c
             if f8 and wide:
                 wo8, swo = self._fp8_weights[l]["w_o"]
                 if not a_mx:
@@ -275,8 +296,9 @@ class BlockStack:
         ops.colsum(dy, gb, ws, R=M, C=C, ld=dy.stride(0), accumulate=acc)
 
     def backward(self, dx: torch.Tensor, dxb: torch.Tensor, saved: dict, acc: Dict[int, bool]) -> torch.Tensor:
-        """dx (fp32) / dxb (16-bit copy): gradient w.r.t. the stack output, [B*T, D].  dx is updated in place layer by
-        layer and on return holds the gradient w.r.t. the stack input; the matching 16-bit copy is RETURNED.
+        """dx (fp32) / dxb (16-bit copy): gradient w.r.t. the stack output, [B*T, D] - or [R, D] on the kept rows when the forward
+        ran with tail_rows.  dx is updated in place layer by layer; the fp32 gradient w.r.t. the stack input is left in
+        saved["dx_in"] (the argument itself unless the tail was compact) and the matching 16-bit copy is RETURNED.
         acc[id(grad_tensor)] says whether that grad buffer already holds a gradient to add to.
 
         The dgrad chain (GEMM -> LN / attention backward -> GEMM ...) is latency-critical and half memory-bound; the
@@ -351,28 +373,65 @@ class BlockStack:
                     return w.wt[name], True
                 return getattr(w, name), not kc
 
-            # ---- MLP branch ----
-            if gr is not None:
-                def f1(sc, dxb=dxb, g=g, gr=gr):
-                    self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
-                leaf(f1)
-            ops.gemm_bf16(dxb, wd("w_proj")[0], b_kcontig=wd("w_proj")[1], act=dact, aux=h, out_bf16=dh, M=M)
-            if gr is not None:
-                def f2(sc, dh=dh, xn2=xn2, gr=gr):
-                    self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
-                leaf(f2)
-            ops.gemm_bf16(dh, wd("w_fc")[0], b_kcontig=wd("w_fc")[1], out_bf16=dsm, M=M)
-            ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
-            ops.layernorm_bwd(dsm, x_mid, w.ln2_w, m2, r2, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_mid,
-                              dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
-                              accumulate=A("ln2_w") if gr is not None else False, ws=ws)
-            dxb = dxb_mid
-            # ---- attention branch ----
-            if gr is not None:
-                def f3(sc, dxb=dxb, a=a, gr=gr):
-                    self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
-                leaf(f3)
-            ops.gemm_bf16(dxb, wd("w_o")[0], b_kcontig=wd("w_o")[1], out_bf16=dsm, M=M)
+            tail = saved.get("tail") if l == L - 1 else None
+            if tail is not None:
+                # the last block's MLP and out-proj ran on the R kept rows only (forward(tail_rows=...)): dx / dxb arrive compact
+                # [R, D]; their backward is compact too, and the gradient re-enters the full-width stream at the attention output
+                # (d a) and at the residual stream (d x_in) of the kept rows
+                R = tail["rows"].numel()
+                a_c, xmid_c, xn2_c, h_c, g_c, st_c = tail["a"], tail["xmid"], tail["xn2"], tail["h"], tail["g"], tail["st"]
+                dh_c = torch.empty(R, Hd, device=dev, dtype=self.dtype)
+                ds_c = torch.empty(R, D, device=dev, dtype=self.dtype)
+                dxb_mid_c = torch.empty(R, D, device=dev, dtype=self.dtype)
+                if gr is not None:
+                    def t1(sc, dxb=dxb, g_c=g_c, gr=gr):
+                        self._wgrad(dxb, g_c, gr["w_proj"], R, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
+                    leaf(t1)
+                ops.gemm_bf16(dxb, wd("w_proj")[0], b_kcontig=wd("w_proj")[1], act=dact, aux=h_c, out_bf16=dh_c, M=R)
+                if gr is not None:
+                    def t2(sc, dh_c=dh_c, xn2_c=xn2_c, gr=gr):
+                        self._wgrad(dh_c, xn2_c, gr["w_fc"], R, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
+                    leaf(t2)
+                ops.gemm_bf16(dh_c, wd("w_fc")[0], b_kcontig=wd("w_fc")[1], out_bf16=ds_c, M=R)
+                ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(R, D)) if gr is not None else None
+                ops.layernorm_bwd(ds_c, xmid_c, w.ln2_w, st_c[0], st_c[1], rows=R, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_mid_c,
+                                  dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
+                                  accumulate=A("ln2_w") if gr is not None else False, ws=ws)
+                if gr is not None:
+                    def t3(sc, dxb_mid_c=dxb_mid_c, a_c=a_c, gr=gr):
+                        self._wgrad(dxb_mid_c, a_c, gr["w_o"], R, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
+                    leaf(t3)
+                ops.gemm_bf16(dxb_mid_c, wd("w_o")[0], b_kcontig=wd("w_o")[1], out_bf16=ds_c, M=R)      # d a of the kept rows
+                dsm.zero_()
+                dsm.index_copy_(0, tail["rows"], ds_c)
+                dx_c = dx                                                 # d x_mid of the kept rows = their share of d x_in
+                dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
+                dx.index_copy_(0, tail["rows"], dx_c)
+                if side is None:
+                    dxb_in = torch.empty(M, D, device=dev, dtype=self.dtype)   # (one-stream mode reuses the caller's dxb, which is compact here)
+            else:
+                # ---- MLP branch ----
+                if gr is not None:
+                    def f1(sc, dxb=dxb, g=g, gr=gr):
+                        self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
+                    leaf(f1)
+                ops.gemm_bf16(dxb, wd("w_proj")[0], b_kcontig=wd("w_proj")[1], act=dact, aux=h, out_bf16=dh, M=M)
+                if gr is not None:
+                    def f2(sc, dh=dh, xn2=xn2, gr=gr):
+                        self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
+                    leaf(f2)
+                ops.gemm_bf16(dh, wd("w_fc")[0], b_kcontig=wd("w_fc")[1], out_bf16=dsm, M=M)
+                ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
+                ops.layernorm_bwd(dsm, x_mid, w.ln2_w, m2, r2, rows=M, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_mid,
+                                  dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
+                                  accumulate=A("ln2_w") if gr is not None else False, ws=ws)
+                dxb = dxb_mid
+                # ---- attention branch ----
+                if gr is not None:
+                    def f3(sc, dxb=dxb, a=a, gr=gr):
+                        self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
+                    leaf(f3)
+                ops.gemm_bf16(dxb, wd("w_o")[0], b_kcontig=wd("w_o")[1], out_bf16=dsm, M=M)
             if geo.head_dim == 64:
                 ops.attention_bwd(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], a, lse[l], dsm, dqkv[:, 0:D],
                                   dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D], B=B, T=T, H=H, causal=geo.causal,
@@ -396,6 +455,7 @@ class BlockStack:
                 # this layer's last gradient kernels are enqueued (weights on the side stream, LayerNorm affines on the main
                 # one): a data-parallel reducer may start this layer's all-reduce now, under the remaining layers' backward
                 hook([t for t in gr.values() if t is not None], [s_ for s_ in (cur, side) if s_ is not None])
+        saved["dx_in"] = dx              # (with a compact tail the full-width fp32 gradient is a new tensor, not the argument)
         if side is not None:
             cur.wait_stream(side)        # every parameter gradient is complete before anyone downstream looks at it
         return dxb

@@ -218,6 +218,11 @@ class CLIP(nn.Module):
         if use_wt:
             self._rt["vis"].refresh_transposed = self._rt["txt"].refresh_transposed = ar.refresh_transposed
 
+    def _tail_rows(self) -> bool:
+        """Each tower pools ONE row per sequence: the last block's out-proj / MLP run on those rows only (BlockStack tail_rows)."""
+        import os
+        return os.environ.get("CCLIP_TAIL_ROWS", "1") != "0"
+
     def _pack_text_rows(self) -> bool:
         import os
         v = getattr(self, "pack_text_rows", None)
@@ -281,8 +286,11 @@ class CLIP(nn.Module):
         ops.vit_embed_ln(patch_out, p["visual.class_embedding"].data, p["visual.positional_embedding"].data,
                          p["visual.ln_pre.weight"].data, p["visual.ln_pre.bias"].data, x, rows=M, T=T, x0=x0,
                          mean=st0[0] if train else None, rstd=st0[1] if train else None)
-        xo = st.forward(x, B, saved=saved)
         rows = (torch.arange(B, device=dev, dtype=torch.int32) * T).contiguous()
+        tail = self._tail_rows()
+        xo = st.forward(x, B, saved=saved, tail_rows=rows.long() if tail else None)     # tail: [B, D], the class rows only
+        if tail:
+            rows = None
         pooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         stp = torch.empty(2, B, device=dev, dtype=torch.float32)
         ops.layernorm_fwd(xo, p["visual.ln_post.weight"].data, p["visual.ln_post.bias"].data, rows=B, row_index=rows,
@@ -311,8 +319,9 @@ class CLIP(nn.Module):
         ops.gemm_f32(c["pooled"].t(), dfeat.t(), g["visual.proj"], beta=1.0 if A("visual.proj") else 0.0)
         dpooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         ops.gemm_f32(dfeat, p["visual.proj"].data, dpooled)
-        dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
-        dxb = torch.zeros(M, D, device=dev, dtype=self.compute_dtype)
+        Mo = c["xo"].shape[0]                       # B when the last block ran on the class rows only (tail), else M
+        dx = torch.zeros(Mo, D, device=dev, dtype=torch.float32)
+        dxb = torch.zeros(Mo, D, device=dev, dtype=self.compute_dtype)
         sc = st.scratch
         ops.layernorm_bwd(dpooled, c["xo"], p["visual.ln_post.weight"].data, c["stp"][0], c["stp"][1], rows=B,
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["visual.ln_post.weight"],
@@ -320,6 +329,7 @@ class CLIP(nn.Module):
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
         st.grad_hook_enabled = S == 1.0         # (under a loss scale the slots are final only after the unscale below)
         dxb = st.backward(dx, dxb, c["saved"], acc)
+        dx = c["saved"]["dx_in"]
         ops.layernorm_bwd(dx, c["x0"], p["visual.ln_pre.weight"].data, c["st0"][0], c["st0"][1], rows=M, dx_out=dx,
                           dx_out_bf16=dxb, dgamma=g["visual.ln_pre.weight"], dbeta=g["visual.ln_pre.bias"],
                           accumulate=A("visual.ln_pre.weight"), ws=sc.floats(ops.layernorm_bwd_ws_floats(M, D)))
@@ -387,15 +397,17 @@ class CLIP(nn.Module):
             ops.text_embed(tok.view(-1), p["token_embedding.weight"].data, p["positional_embedding"].data, xd, rows=M, L=L)
             x = saved["xs"][0, 0] if train else torch.empty(Mp, D, device=dev, dtype=torch.float32)
             torch.index_select(xd, 0, rowmap, out=x)
-            xo = st.forward(x, B, saved=saved, T=L, cu=cu)
             rows = (cu[1:] - 1).contiguous()                                  # each caption's EOT row = its last packed row
+            xo = st.forward(x, B, saved=saved, T=L, cu=cu, tail_rows=rows.long() if self._tail_rows() else None)
         else:
             saved = st.alloc_saved(B, dev, T=L) if train else None
             x = saved["xs"][0, 0] if train else xd
             ops.text_embed(tok.view(-1), p["token_embedding.weight"].data, p["positional_embedding"].data, x, rows=M, L=L)
-            xo = st.forward(x, B, saved=saved, T=L)
             # EOT = largest id in the row (openai/CLIP: x[arange, text.argmax(-1)]); integer index math only
             rows = (torch.arange(B, device=dev) * L + eot).to(torch.int32).contiguous()
+            xo = st.forward(x, B, saved=saved, T=L, tail_rows=rows.long() if self._tail_rows() else None)
+        if self._tail_rows():
+            rows = None                                                       # xo is [B, D]: the EOT rows, in order
         rows_dense = (torch.arange(B, device=dev) * L + eot).to(torch.int32)
         pooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         stp = torch.empty(2, B, device=dev, dtype=torch.float32)
@@ -443,8 +455,9 @@ class CLIP(nn.Module):
         dpooled = torch.empty(B, D, device=dev, dtype=torch.float32)
         ops.gemm_f32(dfeat, p["text_projection"].data, dpooled)
         Mp = c["Mp"]                                  # rows the tower ran on (= M unless the batch was packed)
-        dx = torch.zeros(Mp, D, device=dev, dtype=torch.float32)
-        dxb = torch.zeros(Mp, D, device=dev, dtype=self.compute_dtype)
+        Mo = c["xo"].shape[0]                         # B when the last block ran on the EOT rows only (tail)
+        dx = torch.zeros(Mo, D, device=dev, dtype=torch.float32)
+        dxb = torch.zeros(Mo, D, device=dev, dtype=self.compute_dtype)
         sc = st.scratch
         ops.layernorm_bwd(dpooled, c["xo"], p["ln_final.weight"].data, c["stp"][0], c["stp"][1], rows=B,
                           row_index=c["rows"], dx_out=dx, dx_out_bf16=dxb, dgamma=g["ln_final.weight"],
@@ -452,6 +465,7 @@ class CLIP(nn.Module):
                           ws=sc.floats(ops.layernorm_bwd_ws_floats(B, D)))
         st.grad_hook_enabled = S == 1.0
         dxb = st.backward(dx, dxb, c["saved"], acc)
+        dx = c["saved"]["dx_in"]
         if c["rowmap"] is not None:                   # back to dense rows for the (dense) embedding gradients; dead rows stay zero
             dxp, dx = dx, torch.zeros(M, D, device=dev, dtype=torch.float32)
             dx.index_copy_(0, c["rowmap"], dxp)

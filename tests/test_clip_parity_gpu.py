@@ -461,6 +461,35 @@ def test_image_lanes_are_bit_identical_to_the_whole_batch(monkeypatch):
     assert torch.equal(lanes, whole) and torch.equal(both, whole)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_last_block_on_the_pooled_rows_only(dtype, monkeypatch):
+    """Each tower pools one row per sequence (class token / EOT token), so the last block's out-proj, LayerNorm and MLP run on
+    those rows only (BlockStack tail_rows; default) - against CCLIP_TAIL_ROWS=0, where they run on every row: identical
+    features and loss (the kept rows see the same arithmetic), gradients equal up to the weight gradients' summation partition
+    (the dropped rows' upstream gradient is exactly zero)."""
+    import clip
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    for name, B in (("test-small", 6), ("ViT-B/32", 48)):
+        geo = MODELS[name]
+        img = synthetic_images(B, geo, 1).cuda()
+        txt = synthetic_text(B, geo, 2).cuda()
+        outs = []
+        for tail in ("0", "1"):
+            monkeypatch.setenv("CCLIP_TAIL_ROWS", tail)
+            model = clip.build_model(init_state_dict(geo, 7), dtype).cuda().train()
+            with torch.no_grad():
+                fi, ft = model.encode_image(img), model.encode_text(txt)
+            li, lt = model(img, txt)
+            loss = _ce(li, lt)
+            loss.backward()
+            outs.append((fi, ft, li.detach(), loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), name
+        assert torch.equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
+        assert set(outs[0][4]) == set(outs[1][4])
+        worst = max((rel(outs[1][4][n], outs[0][4][n]), n) for n in outs[0][4])
+        assert worst[0] < 2e-3, (name, worst)
+
+
 def test_empty_and_single_row_batches():
     """Edge cases of the reference's call sites: an empty image folder (CLIP/predict.py batches whatever it finds) gives
     empty [0, embed] features, and a batch of one matches row 0 of the same inputs encoded in a larger batch."""
