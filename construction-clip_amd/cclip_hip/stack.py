@@ -214,14 +214,14 @@ class BlockStack:
                 assert not a_mx
                 a_c = a.index_select(0, tail_rows)
                 xmid_c = torch.empty(R, D, device=dev, dtype=torch.float32)
-                ops.gemm_bf16(a_c, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in.index_select(0, tail_rows), out_f32=xmid_c, M=R)
+                ops.gemm_bf16(a_c, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in.index_select(0, tail_rows), out_f32=xmid_c, M=R, tile_config=1)
                 tb = torch.empty(R, D + 2 * Hd, device=dev, dtype=self.dtype)            # xn2 | h | g of the kept rows
                 xn2_c, h_c, g_c = tb[:, 0:D], tb[:, D:D + Hd], tb[:, D + Hd:D + 2 * Hd]
                 st_c = torch.empty(2, R, device=dev, dtype=torch.float32)
                 ops.layernorm_fwd(xmid_c, w.ln2_w, w.ln2_b, rows=R, out_bf16=xn2_c, mean=st_c[0], rstd=st_c[1])
-                ops.gemm_bf16(xn2_c, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g_c, out_pre=h_c if train else None, M=R)
+                ops.gemm_bf16(xn2_c, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g_c, out_pre=h_c if train else None, M=R, tile_config=1)
                 xout_c = torch.empty(R, D, device=dev, dtype=torch.float32)
-                ops.gemm_bf16(g_c, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=xmid_c, out_f32=xout_c, M=R)
+                ops.gemm_bf16(g_c, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=xmid_c, out_f32=xout_c, M=R, tile_config=1)
                 if train:
                     saved["tail"] = dict(rows=tail_rows, a=a_c, xmid=xmid_c, xn2=xn2_c, h=h_c, g=g_c, st=st_c)
                 return xout_c
@@ -278,7 +278,7 @@ class BlockStack:
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool, scratch=None,
-               gb: Optional[torch.Tensor] = None, acc_b: bool = False):
+               gb: Optional[torch.Tensor] = None, acc_b: bool = False, fixed: bool = False):
         """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out].
         gb: the layer's bias gradient (+)= column sums of dy: dy is an operand of this GEMM (A for nn.Linear weights, B for
         Conv1D ones), so the sums ride on the same launch - one extra MFMA per tile row / column against an all-ones fragment
@@ -286,6 +286,14 @@ class BlockStack:
         lin = self.geo.linear_layout
         a, b = (dy, xin) if lin else (xin, dy)
         n_out, k_in = gw.shape
+        if fixed:
+            # the compact tail of the last block (a batch's worth of rows): 128x128 tiles and the formula split, no table lookup and
+            # no timing - these GEMMs are microseconds, and their row count is the batch size, which the table need not know
+            sp = wgrad_splits(n_out, k_in, M)
+            ws = (scratch or self.scratch).floats(sp * (n_out * k_in + max(n_out, k_in))) if sp > 1 else None
+            ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw, tile_config=1,
+                          split_k=sp, split_ws=ws, colsum_out=gb, colsum_accumulate=acc_b, colsum_of_b=not lin)
+            return
         ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
                       split_candidates=wgrad_candidates(n_out, k_in, M), scratch=(scratch or self.scratch).floats,
                       colsum_out=gb, colsum_accumulate=acc_b, colsum_of_b=not lin)
@@ -385,23 +393,23 @@ class BlockStack:
                 dxb_mid_c = torch.empty(R, D, device=dev, dtype=self.dtype)
                 if gr is not None:
                     def t1(sc, dxb=dxb, g_c=g_c, gr=gr):
-                        self._wgrad(dxb, g_c, gr["w_proj"], R, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
+                        self._wgrad(dxb, g_c, gr["w_proj"], R, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr), fixed=True)
                     leaf(t1)
-                ops.gemm_bf16(dxb, wd("w_proj")[0], b_kcontig=wd("w_proj")[1], act=dact, aux=h_c, out_bf16=dh_c, M=R)
+                ops.gemm_bf16(dxb, wd("w_proj")[0], b_kcontig=wd("w_proj")[1], act=dact, aux=h_c, out_bf16=dh_c, M=R, tile_config=1)
                 if gr is not None:
                     def t2(sc, dh_c=dh_c, xn2_c=xn2_c, gr=gr):
-                        self._wgrad(dh_c, xn2_c, gr["w_fc"], R, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
+                        self._wgrad(dh_c, xn2_c, gr["w_fc"], R, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr), fixed=True)
                     leaf(t2)
-                ops.gemm_bf16(dh_c, wd("w_fc")[0], b_kcontig=wd("w_fc")[1], out_bf16=ds_c, M=R)
+                ops.gemm_bf16(dh_c, wd("w_fc")[0], b_kcontig=wd("w_fc")[1], out_bf16=ds_c, M=R, tile_config=1)
                 ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(R, D)) if gr is not None else None
                 ops.layernorm_bwd(ds_c, xmid_c, w.ln2_w, st_c[0], st_c[1], rows=R, dx_res=dx, dx_out=dx, dx_out_bf16=dxb_mid_c,
                                   dgamma=gr["ln2_w"] if gr is not None else None, dbeta=gr["ln2_b"] if gr is not None else None,
                                   accumulate=A("ln2_w") if gr is not None else False, ws=ws)
                 if gr is not None:
                     def t3(sc, dxb_mid_c=dxb_mid_c, a_c=a_c, gr=gr):
-                        self._wgrad(dxb_mid_c, a_c, gr["w_o"], R, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
+                        self._wgrad(dxb_mid_c, a_c, gr["w_o"], R, A("w_o", gr), sc, gr["b_o"], A("b_o", gr), fixed=True)
                     leaf(t3)
-                ops.gemm_bf16(dxb_mid_c, wd("w_o")[0], b_kcontig=wd("w_o")[1], out_bf16=ds_c, M=R)      # d a of the kept rows
+                ops.gemm_bf16(dxb_mid_c, wd("w_o")[0], b_kcontig=wd("w_o")[1], out_bf16=ds_c, M=R, tile_config=1)      # d a of the kept rows
                 dsm.zero_()
                 dsm.index_copy_(0, tail["rows"], ds_c)
                 dx_c = dx                                                 # d x_mid of the kept rows = their share of d x_in
