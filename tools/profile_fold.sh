@@ -7,6 +7,13 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/prof_r2
 P=profiles
 what=${@:-train caption l14}
+# gpurun MERGES a call's gpurun_out/ into the local one: files of earlier calls of the same pass linger (other process-id prefix);
+# keep only the newest run's files per pass directory, or the fold would average two runs
+for d in $O/*/; do
+  newest=$(ls -t $d*/* 2>/dev/null | head -1); [ -z "$newest" ] && continue
+  pfx=$(basename "$newest" | sed 's/_.*//')
+  for f in $d*/*; do case "$(basename "$f")" in ${pfx}_*) ;; *) rm -f "$f" ;; esac; done
+done
 stats() { cp "$(ls -t $O/$1/*/*kernel_stats.csv | head -1)" $P/$2; }      # newest (gpurun merges: older calls' files may linger locally)
 line() { grep '^{"metric"' $O/$1.log | tail -1 > $P/$2; }
 for w in $what; do
