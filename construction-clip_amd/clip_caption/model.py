@@ -539,14 +539,15 @@ class ClipCaptionModel(nn.Module):
 
     # ---- shared forward to the final hidden states ----
     def _hidden_forward(self, x: torch.Tensor, B: int, S: int, mask: Optional[torch.Tensor], saved: Optional[dict],
-                        cu: Optional[torch.Tensor] = None, rowmap: Optional[torch.Tensor] = None):
+                        cu: Optional[torch.Tensor] = None, rowmap: Optional[torch.Tensor] = None,
+                        tail_rows: Optional[torch.Tensor] = None):
         keep = None
         if mask is not None:
             keep = mask.detach().to(torch.float32).contiguous()
             assert keep.shape == (B, S), f"attention_mask {tuple(mask.shape)} vs sequence {(B, S)}"
             if rowmap is not None:
                 keep = keep.view(-1)[rowmap].contiguous()              # packed rows: the mask entries of the live positions
-        return self._stack.forward(x, B, saved=saved, key_keep=keep, T=S, cu=cu)
+        return self._stack.forward(x, B, saved=saved, key_keep=keep, T=S, cu=cu, tail_rows=tail_rows)
 
     def _pack_rows(self) -> bool:
         import os
@@ -557,7 +558,7 @@ class ClipCaptionModel(nn.Module):
         """ln_f on the selected rows + lm_head (tied wte): logits fp32 [len(rows), V]."""
         ar = self._arena
         p = ar.params
-        R, D = rows.numel(), self.model_embedding_size
+        R, D = (rows.numel() if rows is not None else xo.shape[0]), self.model_embedding_size
         dev = xo.device
         xf = torch.empty(R, D, device=dev, dtype=self.compute_dtype)
         st = torch.empty(2, R, device=dev, dtype=torch.float32)
@@ -724,9 +725,19 @@ class ClipCaptionModel(nn.Module):
             x = saved["xs"][0, 0] if train else torch.empty(B * S, D, device=dev, dtype=torch.float32)
             ops.caption_embed(proj, ids, p["model.transformer.wte.weight"].data, p["model.transformer.wpe.weight"].data, x,
                               B=B, P=P, Lt=Lt)
-        xo = self._hidden_forward(x, B, S, mask, saved, cu=cu, rowmap=rowmap if cu is not None else None)
+        # The fused loss reads only the rows that predict a target: the LAST block's out-proj / LayerNorm / MLP run on those
+        # rows alone (BlockStack tail_rows; CCLIP_TAIL_ROWS=0 disables) and xo comes back compact, in `lm_rows` order.
+        lm_rows = None
+        if pack and os.environ.get("CCLIP_TAIL_ROWS", "1") != "0":
+            Lc = tokens.shape[1]
+            first = S - Lc - 1                                                    # = P + A - 1 (train.py:356)
+            if cu is not None:
+                lm_rows = cu[:-1].long()[tsel // Lc] + first + tsel % Lc
+            else:
+                lm_rows = (torch.arange(B, device=dev)[:, None] * S + first + torch.arange(Lc, device=dev)[None, :]).reshape(-1)
+        xo = self._hidden_forward(x, B, S, mask, saved, cu=cu, rowmap=rowmap if cu is not None else None, tail_rows=lm_rows)
         ctx = dict(saved=saved, msave=msave, ids=ids, B=B, S=S, Lt=Lt, xo=xo, cu=cu, rowmap=rowmap if cu is not None else None,
-                   tsel=tsel, Mp=Mp)
+                   tsel=tsel, Mp=Mp, compact=lm_rows is not None)
         if train and ops.SCATTER_DETERMINISTIC and dev.type == "cuda" and p["model.transformer.wte.weight"].requires_grad:
             # index tables of the deterministic wte-gradient sum: token ids only, so they are built now on a helper stream, under
             # the forward pass, instead of inside the backward pass (clip/model.py does the same for the text tower)
@@ -774,7 +785,7 @@ class ClipCaptionModel(nn.Module):
         M = c.get("Mp") or B * S                       # rows the stack ran on (packed: the live rows only)
         dev = dlog_b.device
         xf, st = lm
-        R = rows.numel()
+        R = dlog_b.shape[0]
         sc = stack.scratch
         frozen = not p["model.transformer.wte.weight"].requires_grad
 
@@ -796,14 +807,16 @@ class ClipCaptionModel(nn.Module):
             wrote_wte = True
         dxf = torch.empty(R, D, device=dev, dtype=self.compute_dtype)
         ops.gemm_bf16(dlog_b, ar.b[wte_name], b_kcontig=False, out_bf16=dxf)           # dlogits @ wte
-        dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
-        dxb = torch.zeros(M, D, device=dev, dtype=self.compute_dtype)
+        Mo = c["xo"].shape[0]                          # R when the last block ran on the target rows only (compact), else M
+        dx = torch.zeros(Mo, D, device=dev, dtype=torch.float32)
+        dxb = torch.zeros(Mo, D, device=dev, dtype=self.compute_dtype)
         lnf_w, lnf_b = "model.transformer.ln_f.weight", "model.transformer.ln_f.bias"
         ops.layernorm_bwd(dxf, c["xo"], p[lnf_w].data, st[0], st[1], rows=R, row_index=rows, dx_out=dx, dx_out_bf16=dxb,
                           dgamma=None if frozen else g[lnf_w], dbeta=None if frozen else g[lnf_b],
                           accumulate=False if frozen else A(lnf_w),
                           ws=None if frozen else sc.floats(ops.layernorm_bwd_ws_floats(R, D)))
         dxb = stack.backward(dx, dxb, c["saved"], acc)
+        dx = c["saved"]["dx_in"]
         if c.get("rowmap") is not None:                # back to dense [B*S, D] rows for the embedding / mapper gradients
             dxp, dxbp = dx, dxb
             dx = torch.zeros(B * S, D, device=dev, dtype=torch.float32)
@@ -905,9 +918,11 @@ class _CaptionLoss(torch.autograd.Function):
         else:
             rows = (torch.arange(B, device=dev)[:, None] * S + first + torch.arange(Lc, device=dev)[None, :]).reshape(-1).to(torch.int32)
             labels = tokens.reshape(-1).to(torch.int32).contiguous()
+        if c["compact"]:
+            rows = None                                                           # xo holds exactly these rows, in this order
         logits, lm = model._lm_rows(xo, rows, need_grad)
         kept = int((labels != 0).sum().item())                               # mean over non-ignored targets
-        R = rows.numel()
+        R = logits.shape[0]
         loss_rows = torch.empty(R, device=dev, dtype=torch.float32)
         V = logits.shape[1]
         dlog = torch.zeros(R, (V + 7) // 8 * 8, device=dev, dtype=model.compute_dtype)[:, :V] if need_grad else None   # finite pads
