@@ -490,6 +490,36 @@ def test_last_block_on_the_pooled_rows_only(dtype, monkeypatch):
         assert worst[0] < 2e-3, (name, worst)
 
 
+def test_packed_text_rows_edge_lengths():
+    """Packed text rows at the edges: every caption full length (nothing to drop: the dense path runs), an empty prompt next to a full
+    one (EOT at index 1 and at index 76), and a two-caption batch - features equal the dense run's bit for bit."""
+    import clip
+    from clip.weights import MODELS, init_state_dict
+    geo = MODELS["test-small"]
+    V, L = geo.vocab_size, geo.context_length
+    gen = torch.Generator().manual_seed(11)
+
+    def caption(n):                       # SOT, n body tokens, EOT, zeros
+        t = torch.zeros(L, dtype=torch.int32)
+        t[0] = V - 2
+        t[1:1 + n] = torch.randint(1, V - 2, (n,), generator=gen, dtype=torch.int32)
+        t[1 + n] = V - 1
+        return t
+
+    batches = [torch.stack([caption(L - 2) for _ in range(5)]),                       # all full length
+               torch.stack([caption(0), caption(L - 2), caption(3)]),                  # empty, full, short
+               torch.stack([caption(0), caption(1)])]
+    for txt in batches:
+        txt = txt.cuda()
+        outs = []
+        for pack in (False, True):
+            model = clip.build_model(init_state_dict(geo, 7)).cuda().eval()
+            model.pack_text_rows = pack
+            with torch.no_grad():
+                outs.append(model.encode_text(txt))
+        assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[1]).all()
+
+
 def test_empty_and_single_row_batches():
     """Edge cases of the reference's call sites: an empty image folder (CLIP/predict.py batches whatever it finds) gives
     empty [0, embed] features, and a batch of one matches row 0 of the same inputs encoded in a larger batch."""
