@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
   cpu_baseline - the CPU oracle (kind "port": the reference's `clip` package is absent) timed
                  on the host cores, SURVEY.md 8d's procedure (bs 64, 3 warm-up + 5 timed, median): the train step and,
                  beside it, the forward-only encode+logits figure.
-The text tower runs on PACKED rows by default (each caption's positions 0..EOT; `config.text_rows`, `dense_text_rows` leg).
+The text tower runs on PACKED rows by default (each caption's positions 0..EOT; `config.text_rows`) and the last block of each tower on its pooled rows; the `all_rows` leg times the same step with both switched off.
 and, in the default (train, one GPU) run, extra objects timed after the headline steps: `encode_image`
 (images/s + fraction of the bf16 MFMA peak - BASELINE.md's 40 % target), `encode_image_fp8` (the same with the block
 projections in e4m3: BASELINE configs[4]'s path on the headline model), `forward_only`, `parity_mode` (the same step
@@ -343,8 +343,9 @@ def extra_legs(model, image, text, geo, B, args):
                                        note="encode_image with e4m3 qkv / out-proj / fc / c_proj (block-scaled fp8 MFMA), same model and batch, "
                                             "20 iterations; an extra, not the headline precision")
     model.train()
-    if model._pack_text_rows():
-        # the same train step with the text tower on all 77 positions of every caption (what the reference computes)
+    if model._pack_text_rows() or model._tail_rows():
+        # the same train step with every row computed, as the reference's modules do: the text tower on all 77 positions of every
+        # caption and the last block of each tower on every token (both switches off; identical features and loss)
         oo = coptim.AdamW(model, lr=1e-5)
 
         def step_dense():
@@ -355,11 +356,18 @@ def extra_legs(model, image, text, geo, B, args):
             oo.step()
 
         model.pack_text_rows = False
+        prev_tail = os.environ.get("CCLIP_TAIL_ROWS")
+        os.environ["CCLIP_TAIL_ROWS"] = "0"
         t = _time_loop(step_dense, 2, 6)
         model.pack_text_rows = None
-        out["dense_text_rows"] = dict(ms_per_step=round(t * 1e3, 3), pairs_per_s=round(B / t, 1),
-                                      note="the same train step with the text tower run on all 77 positions of every caption "
-                                           "(CCLIP_PACK_TEXT=0; identical features, gradients equal to summation order); 6 iterations")
+        if prev_tail is None:
+            del os.environ["CCLIP_TAIL_ROWS"]
+        else:
+            os.environ["CCLIP_TAIL_ROWS"] = prev_tail
+        out["all_rows"] = dict(ms_per_step=round(t * 1e3, 3), pairs_per_s=round(B / t, 1),
+                               note="the same train step computing every row like the reference's modules: text tower on all 77 positions "
+                                    "of every caption (CCLIP_PACK_TEXT=0) and the last block of each tower on every token "
+                                    "(CCLIP_TAIL_ROWS=0); identical features and loss, gradients equal to summation order; 6 iterations")
         del oo
     if args.dtype == "bf16":
         m16 = clip.build_model(init_state_dict(geo, 567), torch.float16).to(image.device).train()
