@@ -357,7 +357,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
                 _TUNE_STATE["derived"] = _TUNE_STATE.get("derived", 0) + 1
                 _DERIVED.add(key)
         if choice is None:
-            cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 7)]
+            cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 7, 8, 10)]
             if split_candidates is None and split_k > 1:
                 d.split_ws = split_ws.data_ptr()
             choice = _autotune(d, key, outs3, cands)

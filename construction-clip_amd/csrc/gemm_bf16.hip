@@ -37,6 +37,8 @@ bool cclip_gemm_launch_cfg3(int lay, int act, dim3 grid, hipStream_t stream, con
 bool cclip_gemm_launch_cfg4(int lay, int act, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg5(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg7(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
+bool cclip_gemm_launch_cfg8(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a, int variant);
+bool cclip_gemm_launch_cfg10(int lay, int act, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmArgs& a);
 
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
@@ -132,12 +134,22 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     a.colsum_ws = splits > 1 ? d->split_ws + (size_t)splits * d->M * d->N : nullptr;
   }
 
+  { static const int dbg = getenv("CCLIP_GEMM_DBG") ? atoi(getenv("CCLIP_GEMM_DBG")) : 0; a.dbg = dbg; }
   int cfg = d->tile_config;
   // M <= 8 against K-strided weights (the projections of a KV-cached decode step): weight-read-bound GEMV path
   if (cfg == 0 && splits == 1 && d->M <= 8 && !d->colsum_out && cclip_gemm_launch_skinny(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a))
     return cclip_launch_status();
   if (cfg == 4) {     // persistent streaming-epilogue kernel: forward layout, full tiles only - refused (not silently replaced) otherwise
     if (splits > 1 || !cclip_gemm_launch_cfg4(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
+    return cclip_launch_status();
+  }
+  if (cfg == 8 || cfg == 9) {   // hand-scheduled 4-wave 256x256 kernel (gemm_bf16_cfg8.hip): forward layout, K % 64 == 0 - refused otherwise
+    const int tiles8 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+    if (splits > 1 || !cclip_gemm_launch_cfg8(d->a_kcontig * 2 + d->b_kcontig, d->act, dim3(tiles8, 1), stream, a, cfg - 8)) return CCLIP_ERR_ARG;
+    return cclip_launch_status();
+  }
+  if (cfg == 10) {              // the same tile as a persistent ring kernel: K % 128 == 0, K >= 256
+    if (splits > 1 || !cclip_gemm_launch_cfg10(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
     return cclip_launch_status();
   }
   if (cfg <= 0 || cfg > 7 || cfg == 6) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);

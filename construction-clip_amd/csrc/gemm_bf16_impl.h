@@ -32,6 +32,7 @@ struct GemmArgs {
   // with split-K the raw partials go to colsum_ws[z][M] and the combine kernel finishes them
   float* colsum_dst = nullptr; float* colsum_ws = nullptr; int colsum_acc = 0;
   int colsum_b = 0;   // 1: row sums of B (size N) instead - the Conv1D weight layout, where dY is the B operand
+  int dbg = 0;        // timing ablations of configurations 8 / 10 (CCLIP_GEMM_DBG; bit 0: no epilogue) - never set by the product path
 };
 
 
@@ -199,6 +200,197 @@ __device__ __forceinline__ void epi_loads(const GemmArgs& p, int row_base, int c
           }
         }
         raux[HAS_AUX ? mi : 0][h] = ax;
+      }
+    }
+  }
+}
+
+// ---- fused epilogue of one wave's (16*MT) x 64 accumulator block whose first row / column are row_base / col_base ----
+// (shared by every tile configuration; `interior`: the whole block tile lies inside M x N, N % 8 == 0, no split-K slab)
+template <int ACT, int MT, bool PRE, int EB, bool HAS_AUX>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT][4], const int row_base, const int col_base,
+                                              const bool interior, const int li, const int g, float (&rres)[EB][2][8],
+                                              bf16x8 (&raux)[HAS_AUX ? EB : 1][2], float (&bsv)[2][8]) {
+  // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
+  if (!PRE) epi_bias(p, col_base, g, bsv);
+  // FAST PATHS.  The general epilogue below serves every combination of outputs, ragged M / N edges and unaligned tails; it
+  // compiles to ~5700 instructions in ~1000 basic blocks (exec-mask branches around every optional piece), of which a wave
+  // executes a couple of thousand per tile - with K = 512 / 768 that is a visible share of a tile's life (PMC, round 2:
+  // 3 VALU + 1 SALU instructions per MFMA over the whole kernel against 0.6 + 0.6 inside the K loop).  Interior tiles of the
+  // four forms the hot path issues take a branch-free straight-line version instead; same arithmetic, same rounding.
+  if (interior) {
+    const long row0 = (long)(row_base + li) * p.ldc + (col_base + 8 * g);
+    if (ACT < CCLIP_ACT_DQUICKGELU && p.out_bf16 && !p.out_f32 && !p.residual && (ACT != CCLIP_ACT_NONE || !p.out_pre)) {
+      // 16-bit output (+ pre-activation when the activation's input is saved for backward): qkv, fc, every plain dgrad
+      bf16* ob = p.out_bf16 + row0;
+      bf16* op = p.out_pre ? p.out_pre + row0 : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[mt][2 * h][r] * p.alpha + bsv[h][r];
+            v[4 + r] = acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r];
+          }
+          const long o = (long)(16 * mt) * p.ldc + 32 * h;
+          if (ACT != CCLIP_ACT_NONE) {
+            if (op) {
+              bf16x8 t;
+#pragma unroll
+              for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+              *(bf16x8*)(op + o) = t;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], 0.f);
+          }
+          bf16x8 t;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+          *(bf16x8*)(ob + o) = t;
+        }
+      return;
+    }
+    if (ACT == CCLIP_ACT_NONE && p.out_f32 && p.residual && !p.out_bf16 && !p.out_pre && p.ldr == p.ldc) {
+      // fp32 residual stream: out = alpha*acc + bias + residual (usually in place): out-proj, c_proj.  The 64x64-per-wave
+      // configurations fetched the residual rows before the K loop (rres); the others load them here, two m-tiles per batch
+      const float* rp = p.residual + row0;
+      float* of = p.out_f32 + row0;
+#pragma unroll
+      for (int mb = 0; mb < MT; mb += 2) {
+        float rr[2][2][8];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (PRE) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) rr[mi][h][r] = rres[PRE ? mb + mi : 0][h][r];
+            } else {
+              const long o = (long)(16 * (mb + mi)) * p.ldc + 32 * h;
+              const float4 t0 = *(const float4*)(rp + o), t1 = *(const float4*)(rp + o + 4);
+              rr[mi][h][0] = t0.x; rr[mi][h][1] = t0.y; rr[mi][h][2] = t0.z; rr[mi][h][3] = t0.w;
+              rr[mi][h][4] = t1.x; rr[mi][h][5] = t1.y; rr[mi][h][6] = t1.z; rr[mi][h][7] = t1.w;
+            }
+          }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int mt = mb + mi;
+            const long o = (long)(16 * mt) * p.ldc + 32 * h;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[mt][2 * h][r] * p.alpha + bsv[h][r];
+              v[4 + r] = acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += rr[mi][h][r];
+            *(float4*)(of + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(of + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+      }
+      return;
+    }
+    if (HAS_AUX && p.out_bf16 && !p.out_f32 && !p.out_pre && !p.residual && p.ldaux == p.ldc) {
+      // activation derivative: out16 = act'(aux) * (alpha*acc + bias): the dgrad of the MLP's second projection
+      const bf16* ap = p.aux + row0;
+      bf16* ob = p.out_bf16 + row0;
+#pragma unroll
+      for (int mb = 0; mb < MT; mb += 2) {
+        bf16x8 ax[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            ax[mi][h] = PRE ? raux[(PRE && HAS_AUX) ? mb + mi : 0][h] : *(const bf16x8*)(ap + (long)(16 * (mb + mi)) * p.ldc + 32 * h);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int mt = mb + mi;
+            bf16x8 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              t[r] = (bf16)act_apply<ACT>(acc[mt][2 * h][r] * p.alpha + bsv[h][r], (float)ax[mi][h][r]);
+              t[4 + r] = (bf16)act_apply<ACT>(acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r], (float)ax[mi][h][4 + r]);
+            }
+            *(bf16x8*)(ob + (long)(16 * mt) * p.ldc + 32 * h) = t;
+          }
+      }
+      return;
+    }
+  }
+  // General epilogue.  Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then
+  // the math and the stores - one memory round trip per batch instead of one per 8-column run.
+#pragma unroll
+  for (int mb = 0; mb < MT; mb += EB) {
+    // pass 1: loads (already in flight since kernel start when PRE)
+    if (!PRE) epi_loads<EB, HAS_AUX, true, true>(p, row_base, col_base, mb, li, g, rres, raux);
+    else if (HAS_AUX) epi_loads<EB, HAS_AUX, true, false>(p, row_base, col_base, mb, li, g, rres, raux);
+    // pass 2: math + stores
+#pragma unroll
+    for (int mi = 0; mi < EB; ++mi) {
+      const int mt = mb + mi;
+      const int m = row_base + 16 * mt + li;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n0 = col_base + 32 * h + 8 * g;
+        if (m >= p.M || n0 >= p.N) continue;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
+        if (p.split_ws) {
+          float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
+          *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+          if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          continue;
+        }
+        const bool full = n0 + 8 <= p.N;        // N need not be a multiple of 8: the last run is handled per element
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bsv[h][r];
+        if (p.out_pre) {
+          bf16* o = p.out_pre + (long)m * p.ldc + n0;
+          if (full) {
+            bf16x8 t;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+            *(bf16x8*)o = t;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+          }
+        }
+        if (ACT != CCLIP_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], (float)raux[HAS_AUX ? mi : 0][h][r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rres[mi][h][r];
+        if (p.out_f32) {
+          float* o = p.out_f32 + (long)m * p.ldc + n0;
+          if (full) {
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = v[r];
+          }
+        }
+        if (p.out_bf16) {
+          bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
+          if (full) {
+            bf16x8 t;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
+            *(bf16x8*)o = t;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
+          }
+        }
       }
     }
   }
@@ -569,190 +761,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
         }
     }
   }
-  // ---- epilogue: lane holds, per (mt, h): 8 consecutive columns n0..n0+7 of row m ----
-  if (!PRE) epi_bias(p, bn0 + wn0, g, bsv);
-  // FAST PATHS.  The general epilogue below serves every combination of outputs, ragged M / N edges and unaligned tails; it
-  // compiles to ~5700 instructions in ~1000 basic blocks (exec-mask branches around every optional piece), of which a wave
-  // executes a couple of thousand per tile - with K = 512 / 768 that is a visible share of a tile's life (PMC, round 2:
-  // 3 VALU + 1 SALU instructions per MFMA over the whole kernel against 0.6 + 0.6 inside the K loop).  Interior tiles of the
-  // four forms the hot path issues take a branch-free straight-line version instead; same arithmetic, same rounding.
-  const bool interior = bm0 + BM_ <= p.M && bn0 + BN_ <= p.N && !(p.N & 7) && !p.split_ws;
-  if (interior) {
-    const long row0 = (long)(bm0 + wm0 + li) * p.ldc + (bn0 + wn0 + 8 * g);
-    if (ACT < CCLIP_ACT_DQUICKGELU && p.out_bf16 && !p.out_f32 && !p.residual && (ACT != CCLIP_ACT_NONE || !p.out_pre)) {
-      // 16-bit output (+ pre-activation when the activation's input is saved for backward): qkv, fc, every plain dgrad
-      bf16* ob = p.out_bf16 + row0;
-      bf16* op = p.out_pre ? p.out_pre + row0 : nullptr;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float v[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[mt][2 * h][r] * p.alpha + bsv[h][r];
-            v[4 + r] = acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r];
-          }
-          const long o = (long)(16 * mt) * p.ldc + 32 * h;
-          if (ACT != CCLIP_ACT_NONE) {
-            if (op) {
-              bf16x8 t;
-#pragma unroll
-              for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-              *(bf16x8*)(op + o) = t;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], 0.f);
-          }
-          bf16x8 t;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-          *(bf16x8*)(ob + o) = t;
-        }
-      return;
-    }
-    if (ACT == CCLIP_ACT_NONE && p.out_f32 && p.residual && !p.out_bf16 && !p.out_pre && p.ldr == p.ldc) {
-      // fp32 residual stream: out = alpha*acc + bias + residual (usually in place): out-proj, c_proj.  The 64x64-per-wave
-      // configurations fetched the residual rows before the K loop (rres); the others load them here, two m-tiles per batch
-      const float* rp = p.residual + row0;
-      float* of = p.out_f32 + row0;
-#pragma unroll
-      for (int mb = 0; mb < MT; mb += 2) {
-        float rr[2][2][8];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (PRE) {
-#pragma unroll
-              for (int r = 0; r < 8; ++r) rr[mi][h][r] = rres[PRE ? mb + mi : 0][h][r];
-            } else {
-              const long o = (long)(16 * (mb + mi)) * p.ldc + 32 * h;
-              const float4 t0 = *(const float4*)(rp + o), t1 = *(const float4*)(rp + o + 4);
-              rr[mi][h][0] = t0.x; rr[mi][h][1] = t0.y; rr[mi][h][2] = t0.z; rr[mi][h][3] = t0.w;
-              rr[mi][h][4] = t1.x; rr[mi][h][5] = t1.y; rr[mi][h][6] = t1.z; rr[mi][h][7] = t1.w;
-            }
-          }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int mt = mb + mi;
-            const long o = (long)(16 * mt) * p.ldc + 32 * h;
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = acc[mt][2 * h][r] * p.alpha + bsv[h][r];
-              v[4 + r] = acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += rr[mi][h][r];
-            *(float4*)(of + o) = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(of + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          }
-      }
-      return;
-    }
-    if (HAS_AUX && p.out_bf16 && !p.out_f32 && !p.out_pre && !p.residual && p.ldaux == p.ldc) {
-      // activation derivative: out16 = act'(aux) * (alpha*acc + bias): the dgrad of the MLP's second projection
-      const bf16* ap = p.aux + row0;
-      bf16* ob = p.out_bf16 + row0;
-#pragma unroll
-      for (int mb = 0; mb < MT; mb += 2) {
-        bf16x8 ax[2][2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-            ax[mi][h] = PRE ? raux[(PRE && HAS_AUX) ? mb + mi : 0][h] : *(const bf16x8*)(ap + (long)(16 * (mb + mi)) * p.ldc + 32 * h);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int mt = mb + mi;
-            bf16x8 t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              t[r] = (bf16)act_apply<ACT>(acc[mt][2 * h][r] * p.alpha + bsv[h][r], (float)ax[mi][h][r]);
-              t[4 + r] = (bf16)act_apply<ACT>(acc[mt][2 * h + 1][r] * p.alpha + bsv[h][4 + r], (float)ax[mi][h][4 + r]);
-            }
-            *(bf16x8*)(ob + (long)(16 * mt) * p.ldc + 32 * h) = t;
-          }
-      }
-      return;
-    }
-  }
-  // General epilogue.  Two passes per batch of m-tiles: first ALL global loads of the batch (residual / aux) are issued, then
-  // the math and the stores - one memory round trip per batch instead of one per 8-column run.
-#pragma unroll
-  for (int mb = 0; mb < MT; mb += EB) {
-    // pass 1: loads (already in flight since kernel start when PRE)
-    if (!PRE) epi_loads<EB, HAS_AUX, true, true>(p, bm0 + wm0, bn0 + wn0, mb, li, g, rres, raux);
-    else if (HAS_AUX) epi_loads<EB, HAS_AUX, true, false>(p, bm0 + wm0, bn0 + wn0, mb, li, g, rres, raux);
-    // pass 2: math + stores
-#pragma unroll
-    for (int mi = 0; mi < EB; ++mi) {
-      const int mt = mb + mi;
-      const int m = bm0 + wm0 + 16 * mt + li;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int n0 = bn0 + wn0 + 32 * h + 8 * g;
-        if (m >= p.M || n0 >= p.N) continue;
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
-        if (p.split_ws) {
-          float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
-          *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-          if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          continue;
-        }
-        const bool full = n0 + 8 <= p.N;        // N need not be a multiple of 8: the last run is handled per element
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bsv[h][r];
-        if (p.out_pre) {
-          bf16* o = p.out_pre + (long)m * p.ldc + n0;
-          if (full) {
-            bf16x8 t;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-            *(bf16x8*)o = t;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
-          }
-        }
-        if (ACT != CCLIP_ACT_NONE) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = act_apply<ACT>(v[r], (float)raux[HAS_AUX ? mi : 0][h][r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += rres[mi][h][r];
-        if (p.out_f32) {
-          float* o = p.out_f32 + (long)m * p.ldc + n0;
-          if (full) {
-            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = v[r];
-          }
-        }
-        if (p.out_bf16) {
-          bf16* o = p.out_bf16 + (long)m * p.ldc + n0;
-          if (full) {
-            bf16x8 t;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) t[r] = (bf16)v[r];
-            *(bf16x8*)o = t;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) if (n0 + r < p.N) o[r] = (bf16)v[r];
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<ACT, MT, PRE, EB, HAS_AUX>(p, acc, bm0 + wm0, bn0 + wn0,
+                                           bm0 + BM_ <= p.M && bn0 + BN_ <= p.N && !(p.N & 7) && !p.split_ws, li, g, rres, raux, bsv);
 }
 
 // launcher for one tile configuration; instantiates exactly the (layout, activation) pairs the hot path issues

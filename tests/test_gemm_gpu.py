@@ -108,6 +108,116 @@ def test_gemm_epilogues(act, akc, bkc, cfg):
     _report(f"act{act} pre", outp, pre, 1e-2)
 
 
+@pytest.mark.parametrize("cfg", [8, 9])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (450, 768, 768), (1000, 2304, 768), (264, 200, 192),
+                                   (300, 264, 3072), (2048, 512, 512)])
+def test_gemm_cfg8_plain_and_bit_exact(M, N, K, cfg):
+    """Configuration 8 / 9 (four 128x128 waves, hand-scheduled asm K loop): forward layout, K % 64 == 0.  It sums each output's
+    products in the same order as the 256x256 configuration 3 (k ascending, 32 per MFMA) -> bit-identical results."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    B = torch.randn((N, K), device="cuda", generator=g).bfloat16()
+    ref = A.float() @ B.float().t()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    out3 = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, out_f32=out, tile_config=cfg)
+    ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, out_f32=out3, tile_config=3)
+    torch.cuda.synchronize()
+    _report(f"plain {M}x{N}x{K} cfg{cfg}", out, ref, 2e-3)
+    assert torch.equal(out, out3), "configuration 8 must reproduce configuration 3 bit for bit"
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 768), (450, 768, 768), (1000, 2304, 768), (264, 200, 384),
+                                   (300, 264, 3072), (2048, 512, 512), (70000, 512, 256), (25600, 768, 768)])
+def test_gemm_cfg10_persistent_ring_bit_exact(M, N, K):
+    """Configuration 10 (persistent 4-wave ring kernel; K % 128 == 0): every work-group walks several tiles when there are more
+    tiles than CUs (the last two shapes), the DMA stream crossing tile boundaries.  Same summation order as configuration 3."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    B = torch.randn((N, K), device="cuda", generator=g).bfloat16()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    out3 = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, out_f32=out, tile_config=10)
+    ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, out_f32=out3, tile_config=3)
+    torch.cuda.synchronize()
+    if M * N <= 1 << 22:
+        _report(f"plain {M}x{N}x{K} cfg10", out, A.float() @ B.float().t(), 2e-3)
+    assert torch.equal(out, out3), "configuration 10 must reproduce configuration 3 bit for bit"
+    # run it again into the same buffer behind another launch: no state may leak from launch to launch
+    out.fill_(float("nan"))
+    ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, out_f32=out, tile_config=10)
+    assert torch.equal(out, out3)
+
+
+@pytest.mark.parametrize("cfg", [8, 9, 10])
+@pytest.mark.parametrize("act", [0, 1, 16])
+def test_gemm_cfg8_epilogues(act, cfg):
+    ops = _ops()
+    for (M, N, K) in ((300, 264, 256), (512, 512, 256)):       # ragged edges (general epilogue) and interior tiles (fast paths)
+        g = torch.Generator(device="cuda").manual_seed(act)
+        A = (torch.randn(M, K, device="cuda", generator=g) * 0.1).bfloat16()
+        B = torch.randn((N, K), device="cuda", generator=g).bfloat16()
+        bias = torch.randn(N, device="cuda", generator=g)
+        res = torch.randn(M, N, device="cuda", generator=g)
+        aux = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+        pre = 0.5 * (A.float() @ B.float().t()) + bias
+        ref = _ref_act(pre, act, aux) + res
+        out = torch.full((M, N), float("nan"), device="cuda")
+        outb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        outp = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, alpha=0.5, bias=bias, act=act, aux=aux if act >= 16 else None,
+                      residual=res, out_f32=out, out_bf16=outb, out_pre=outp, tile_config=cfg)
+        torch.cuda.synchronize()
+        _report(f"act{act} f32", out, ref, 2e-3)
+        _report(f"act{act} bf16", outb, ref, 1e-2)
+        _report(f"act{act} pre", outp, pre, 1e-2)
+        # the fast-path forms the hot path issues: 16-bit out (+ pre-activation), fp32 residual in place, activation derivative -
+        # configurations 8 / 10 stage them through LDS for row-contiguous stores: same arithmetic, so bit-identical to configuration 3
+        if act in (0, 1):
+            got = []
+            for c in (cfg, 3):
+                ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+                op = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if act else None
+                ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, alpha=0.5, bias=bias, act=act, out_bf16=ob, out_pre=op, tile_config=c)
+                got.append((ob, op))
+            _report(f"fast16 act{act}", got[0][0], _ref_act(pre, act, None), 1e-2)
+            assert torch.equal(got[0][0], got[1][0])
+            if act:
+                _report(f"fast16 pre act{act}", got[0][1], pre, 1e-2)
+                assert torch.equal(got[0][1], got[1][1])
+                ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)          # inference form: activation, no saved pre-activation
+                ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, alpha=0.5, bias=bias, act=act, out_bf16=ob, tile_config=cfg)
+                assert torch.equal(ob, got[1][0])
+        if act == 0:
+            x, x3 = res.clone(), res.clone()
+            ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, alpha=0.5, bias=bias, residual=x, out_f32=x, tile_config=cfg)
+            ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, alpha=0.5, bias=bias, residual=x3, out_f32=x3, tile_config=3)
+            _report("fast residual", x, pre + res, 2e-3)
+            assert torch.equal(x, x3)
+        if act == 16:
+            ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            ob3 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, alpha=0.5, bias=bias, act=act, aux=aux, out_bf16=ob, tile_config=cfg)
+            ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, alpha=0.5, bias=bias, act=act, aux=aux, out_bf16=ob3, tile_config=3)
+            _report("fast dact", ob, _ref_act(pre, act, aux), 1e-2)
+            assert torch.equal(ob, ob3)
+
+
+def test_gemm_cfg8_refuses_what_it_does_not_implement():
+    ops = _ops()
+    A = torch.randn(256, 96, device="cuda").bfloat16()
+    B = torch.randn(256, 96, device="cuda").bfloat16()
+    out = torch.empty(256, 256, device="cuda")
+    with pytest.raises(RuntimeError):        # K % 64 != 0
+        ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, out_f32=out, tile_config=8)
+    Bt = torch.randn(128, 256, device="cuda").bfloat16()
+    A2 = torch.randn(256, 128, device="cuda").bfloat16()
+    with pytest.raises(RuntimeError):        # K-strided B
+        ops.gemm_bf16(A2, Bt, a_kcontig=True, b_kcontig=False, out_f32=out, tile_config=8)
+
+
 def test_gemm_residual_inplace_and_ld():
     """out_f32 aliases residual (x += ...), outputs with a row stride larger than N."""
     ops = _ops()
