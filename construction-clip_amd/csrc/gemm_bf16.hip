@@ -143,12 +143,12 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
     if (splits > 1 || !cclip_gemm_launch_cfg4(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
     return cclip_launch_status();
   }
-  if (cfg == 8 || cfg == 9) {   // hand-scheduled 4-wave 256x256 kernel (gemm_bf16_cfg8.hip): forward layout, K % 64 == 0 - refused otherwise
+  if (cfg == 8) {   // hand-scheduled 4-wave 256x256 kernel (gemm_bf16_cfg8.hip): forward layout, K % 64 == 0 - refused otherwise
     const int tiles8 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
-    if (splits > 1 || !cclip_gemm_launch_cfg8(d->a_kcontig * 2 + d->b_kcontig, d->act, dim3(tiles8, 1), stream, a, cfg - 8)) return CCLIP_ERR_ARG;
+    if (splits > 1 || !cclip_gemm_launch_cfg8(d->a_kcontig * 2 + d->b_kcontig, d->act, dim3(tiles8, 1), stream, a, 0)) return CCLIP_ERR_ARG;
     return cclip_launch_status();
   }
-  if (cfg == 10) {              // the same tile as a persistent ring kernel: K % 128 == 0, K >= 256
+  if (cfg == 10) {              // the same tile and K loop as a persistent kernel (cross-tile operand prefetch): K % 64 == 0, K >= 192
     if (splits > 1 || !cclip_gemm_launch_cfg10(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
     return cclip_launch_status();
   }

@@ -108,7 +108,7 @@ def test_gemm_epilogues(act, akc, bkc, cfg):
     _report(f"act{act} pre", outp, pre, 1e-2)
 
 
-@pytest.mark.parametrize("cfg", [8, 9])
+@pytest.mark.parametrize("cfg", [8])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (450, 768, 768), (1000, 2304, 768), (264, 200, 192),
                                    (300, 264, 3072), (2048, 512, 512)])
 def test_gemm_cfg8_plain_and_bit_exact(M, N, K, cfg):
@@ -151,7 +151,7 @@ def test_gemm_cfg10_persistent_ring_bit_exact(M, N, K):
     assert torch.equal(out, out3)
 
 
-@pytest.mark.parametrize("cfg", [8, 9, 10])
+@pytest.mark.parametrize("cfg", [8, 10])
 @pytest.mark.parametrize("act", [0, 1, 16])
 def test_gemm_cfg8_epilogues(act, cfg):
     ops = _ops()

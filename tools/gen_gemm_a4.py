@@ -197,158 +197,144 @@ def emit(variant, name):
 
 
 # ======================================================================================================================
-# Persistent ring kernel (tile configuration 10): BK = 32 steps through a ring of four 32 KiB LDS slots, the DMA stream
-# runs FOUR steps ahead of the MFMAs and does not stop at tile boundaries (the last four steps of a tile stage the first four
-# steps of the work-group's next tile), so neither the fill latency nor the next tile's first operands are exposed.
-#   LDS slot (32 KiB) = [A: 256 rows x 64 B][B: 256 rows x 64 B]; 16-byte chunk g (k = 8g..8g+7) of row r sits at
-#   r*64 + ((g ^ ((-(r >> 2)) & 3)) << 4): conflict-free for the ds_read_b128 lane groups (MI355X_MICROARCH.md, LDS).
-#   step j: s_waitcnt vmcnt(16); s_barrier  -> step j+1's slot is visible, everybody is done reading slot j
-#           64 MFMAs on fragment set j&1  +  16 reads of slot j+1 -> set (j+1)&1  +  8 DMA pieces of step j+4 -> slot j
-# Register map: v[0:63] / v[64:127] fragment sets; v[128:131] / v[132:135] A / B DMA offsets of the current tile,
-# v[136:143] the same for the next tile; v144/v145 A read base (slots 0-1 / slots 2-3), v146/v147 the B ones;
-# s[60:61], s[62:63] A / B source of the current tile's next step to stage, s[66:67], s[68:69] the next tile's; s64 loop
-# counter; s65 M0 base (LDS base + wave * 1024).
-SLOT = 32768
-
-
-def r_afrag(s, mt):
-    return afrag(s, mt)
-
-
-def r_reads(slot, s):
-    """16 ds_read_b128 of ring slot `slot` into fragment set s."""
-    va, vb = (144, 146) if slot < 2 else (145, 147)
-    so = (slot & 1) * SLOT
+# Persistent form (tile configuration 10): the same BK = 64 rotated loop, but a work-group walks MANY tiles and its DMA stream
+# does not stop at a tile boundary: the last iteration of a tile stages K-tiles 0 and 1 of the work-group's NEXT tile (into the
+# two stages as they fall free), so the next tile finds its first operands in LDS, and the epilogue's global stores - younger than
+# those DMAs in the in-order vmcnt queue - are NOT waited for at the next tile's start: COUNTED waits (all but the W youngest,
+# W = the stores the epilogue is known to have issued) let them drain under the next tile's first two K iterations.
+#   extra registers: v[148:163] the next tile's DMA offsets; s[66:67], s[68:69] its A / B source; s70 / s71 the wait selectors of
+#   the tile's first two barriers (0: vmcnt(0), 1: vmcnt(32), 2: vmcnt(48), 3: vmcnt(63)).
+def dma_pairs_next():
     out = []
-    for nt in range(8):
-        out.append(f"ds_read_b128 {bfrag(s, nt)}, v{vb} offset:{so + 16384 + 1024 * nt}")
-    for mt in range(8):
-        out.append(f"ds_read_b128 {afrag(s, mt)}, v{va} offset:{so + 1024 * mt}")
+    for i in range(8):
+        out.append((f"s_add_u32 m0, s65, {4096 * i}", f"global_load_lds_dwordx4 v{148 + i}, s[66:67]"))
+    for i in range(8):
+        out.append((f"s_add_u32 m0, s65, {32768 + 4096 * i}", f"global_load_lds_dwordx4 v{156 + i}, s[68:69]"))
     return out
 
 
-def r_dma(slot, nxt):
-    """8 (M0 setup, DMA) pairs of one step into ring slot `slot`: 4 pieces of the A half-tile, 4 of the B half-tile."""
-    ob = 136 if nxt else 128
-    sa, sb = ("s[66:67]", "s[68:69]") if nxt else ("s[60:61]", "s[62:63]")
-    out = []
-    for i in range(4):
-        out.append((f"s_add_u32 m0, s65, {slot * SLOT + 4096 * i}", f"global_load_lds_dwordx4 v{ob + i}, {sa}"))
-    for i in range(4):
-        out.append((f"s_add_u32 m0, s65, {slot * SLOT + 16384 + 4096 * i}", f"global_load_lds_dwordx4 v{ob + 4 + i}, {sb}"))
-    return out
+ADVANCE_NEXT = ["s_add_u32 s66, s66, 128", "s_addc_u32 s67, s67, 0", "s_add_u32 s68, s68, 128", "s_addc_u32 s69, s69, 0",
+                "s_xor_b32 s65, s65, 0x10000"]
 
 
-def r_advance(nxt):
-    if nxt:
-        return ["s_add_u32 s66, s66, 64", "s_addc_u32 s67, s67, 0", "s_add_u32 s68, s68, 64", "s_addc_u32 s69, s69, 0"]
-    return ["s_add_u32 s60, s60, 64", "s_addc_u32 s61, s61, 0", "s_add_u32 s62, s62, 64", "s_addc_u32 s63, s63, 0"]
-
-
-def r_mfma(s, zero, order):
+def mfma_zero(s, order):
     out = []
     rng = [(mt, nt) for mt in range(8) for nt in range(8)] if order == "mt_outer" else [(mt, nt) for nt in range(8) for mt in range(8)]
     for mt, nt in rng:
-        c = "0" if zero else acc(mt, nt)
-        out.append(f"{MFMA} {acc(mt, nt)}, {bfrag(s, nt)}, {afrag(s, mt)}, {c}")
+        out.append(f"{MFMA} {acc(mt, nt)}, {bfrag(s, nt)}, {afrag(s, mt)}, 0")
     return out
 
 
-def r_step(slot, zero, nxt, variant, read_next=True, first=False):
-    """One ring step on slot `slot`: wait + barrier, 64 MFMAs on set slot&1 with the reads of the following slot and the DMA
-    group of the step four ahead dealt into the gaps."""
-    L = []
-    if not first:
-        L += ["s_waitcnt vmcnt(16)", "s_barrier"]
+def p_phase_R(dma, variant, rd=True, set_=1):
+    """64 MFMAs on set 1 + a DMA group (None / 'cur' / 'next') + (rd) the reads of (kt, k-step 0) into set 0."""
     fill = {}
-    if read_next:
-        rd = r_reads((slot + 1) & 3, (slot + 1) & 1)
-        for r, ins in enumerate(rd):
-            fill.setdefault(variant["read_gap0"] + variant["read_stride"] * r, []).append(ins)
-    pairs = r_dma(slot, nxt)
-    for j, (m0, ld) in enumerate(pairs):
-        g0 = variant["dma_gap0"] + variant["dma_stride"] * j
-        fill.setdefault(g0, []).append(m0)
-        fill.setdefault(g0 + 1, []).append(ld)
-    adv = r_advance(nxt)
-    fill.setdefault(62, []).extend(adv[:2])
-    fill.setdefault(63, []).extend(adv[2:])
-    L += phase(r_mfma(slot & 1, zero, variant["order"]), fill)
-    L += ["s_waitcnt lgkmcnt(0)"]
-    return L
+    if dma:
+        pairs = dma_pairs() if dma == "cur" else dma_pairs_next()
+        adv = ADVANCE if dma == "cur" else ADVANCE_NEXT
+        for j, (m0, ld) in enumerate(pairs):
+            fill.setdefault(4 * j, []).append(m0)
+            fill.setdefault(4 * j + 1, []).append(ld)
+        fill.setdefault(62, []).extend(adv[:2])
+        fill.setdefault(63, []).extend(adv[2:])
+    if rd:
+        for r, ins in enumerate(reads(0, 0)):
+            fill.setdefault(4 * (r // 2) + 2 + (r % 2), []).append(ins)
+    return phase(mfma_list(set_, variant["order"]), fill)
 
 
-def ring_first():
-    """Work-group prologue: the DMA groups of steps 0..3 of its first tile (from the 'current tile' registers)."""
-    L = ["s_mov_b64 s[60:61], %[abase]", "s_mov_b64 s[62:63], %[bbase]", "s_mov_b32 s65, %[m0base]", "s_nop 4"]
-    for slot in range(4):
-        for m0, ld in r_dma(slot, False):
+def p_phase_Q(variant, zero=False):
+    fill = {}
+    for r, ins in enumerate(reads(1, 1)):
+        fill.setdefault(2 * r + 1, []).append(ins)
+    for i, t in enumerate(TOGGLE):
+        fill.setdefault(40 + 2 * i, []).append(t)
+    mf = mfma_zero(0, variant["order"]) if zero else mfma_list(0, variant["order"])
+    return phase(mf, fill)
+
+
+def wait_sel(sreg, tag):
+    return [f"s_cmp_eq_u32 {sreg}, 3", f"s_cbranch_scc1 W63{tag}_%=", f"s_cmp_eq_u32 {sreg}, 2", f"s_cbranch_scc1 W48{tag}_%=",
+            f"s_cmp_eq_u32 {sreg}, 1", f"s_cbranch_scc1 W32{tag}_%=", "s_waitcnt vmcnt(0)", f"s_branch WD{tag}_%=",
+            f"W63{tag}_%=:", "s_waitcnt vmcnt(63)", f"s_branch WD{tag}_%=", f"W48{tag}_%=:", "s_waitcnt vmcnt(48)", f"s_branch WD{tag}_%=",
+            f"W32{tag}_%=:", "s_waitcnt vmcnt(32)", f"WD{tag}_%=:"]
+
+
+def pers_first():
+    """Work-group prologue: K-tiles 0 and 1 of its first tile."""
+    L = ["s_mov_b64 s[60:61], %[abase]", "s_mov_b64 s[62:63], %[bbase]", "s_mov_b32 s65, %[m0st]", "s_nop 4"]
+    for _ in range(2):
+        for m0, ld in dma_pairs():
             L += [m0, "s_nop 0", ld]
-        L += r_advance(False)
+        L += ADVANCE
     return L
 
 
-def ring_tile(variant):
-    """One tile: K/32 = 4 (s64 + 2) steps.  Steps 0..3 of this tile are in flight / landed on entry."""
+def pers_tile(variant):
+    """One tile; K-tiles 0 and 1 are staged (or on their way) on entry.  s64 = nkt - 2 >= 1 loop iterations (kt = 1 .. nkt-2)."""
     L = ["s_mov_b64 s[60:61], %[abase]", "s_mov_b64 s[62:63], %[bbase]", "s_mov_b64 s[66:67], %[nabase]", "s_mov_b64 s[68:69], %[nbbase]",
-         "s_mov_b32 s64, %[niter]", "s_mov_b32 s65, %[m0base]"]
-    L += ["s_waitcnt vmcnt(0)", "s_barrier"]
-    L += r_reads(0, 0)
-    L += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
-    # first group of four steps (accumulators start from zero), DMA from the current tile
-    L += r_step(0, True, False, variant, first=True)
-    for u in (1, 2, 3):
-        L += r_step(u, False, False, variant)
-    L += ["s_cmp_eq_u32 s64, 0", "s_cbranch_scc1 RLAST_%="]
-    L += ["RLOOP_%=:"]
-    for u in range(4):
-        L += r_step(u, False, False, variant)
-    L += ["s_sub_u32 s64, s64, 1", "s_cmp_lg_u32 s64, 0", "s_cbranch_scc1 RLOOP_%="]
-    L += ["RLAST_%=:"]
-    for u in range(4):           # last group: the DMA stream is already in the next tile
-        L += r_step(u, False, True, variant, read_next=(u != 3))
-    L += ["s_nop 15", "s_nop 15"]
+         "s_mov_b32 s64, %[niter]", "s_mov_b32 s65, %[m0st]", "s_mov_b32 s70, %[w0]", "s_mov_b32 s71, %[w1]"]
+    L += wait_sel("s70", "A") + ["s_barrier"]
+    L += reads(0, 0) + ["s_waitcnt lgkmcnt(0)"]
+    L += p_phase_Q(variant, zero=True) + ["s_waitcnt lgkmcnt(0)"]
+    # kt = 1: K-tile 1 was staged before the epilogue's stores -> counted wait
+    L += wait_sel("s71", "B") + ["s_barrier"]
+    L += p_phase_R("cur", variant) + ["s_waitcnt lgkmcnt(0)"]
+    L += p_phase_Q(variant) + ["s_waitcnt lgkmcnt(0)"]
+    L += ["s_sub_u32 s64, s64, 1", "s_cmp_eq_u32 s64, 0", "s_cbranch_scc1 PLAST_%="]
+    L += ["PLOOP_%=:", "s_waitcnt vmcnt(0)", "s_barrier"]
+    L += p_phase_R("cur", variant) + ["s_waitcnt lgkmcnt(0)"]
+    L += p_phase_Q(variant) + ["s_waitcnt lgkmcnt(0)"]
+    L += ["s_sub_u32 s64, s64, 1", "s_cmp_lg_u32 s64, 0", "s_cbranch_scc1 PLOOP_%="]
+    L += ["PLAST_%=:", "s_waitcnt vmcnt(0)", "s_barrier"]
+    L += p_phase_R("next", variant) + ["s_waitcnt lgkmcnt(0)"]          # K-tile 0 of the next tile -> the stage of kt - 1
+    L += p_phase_Q(variant) + ["s_waitcnt lgkmcnt(0)", "s_barrier"]     # everybody is done reading the last K-tile's stage
+    L += p_phase_R("next", variant, rd=False)                           # k-step 1 of the last K-tile + K-tile 1 of the next tile
+    L += ["s_mov_b32 %[m0out], s65", "s_nop 15", "s_nop 15"]
     return L
 
 
-def ring_clobbers():
+def pers_clobbers():
     c = ['"memory"', '"vcc"', '"scc"']
-    c += [f'"s{i}"' for i in range(60, 70)]
+    c += [f'"s{i}"' for i in range(60, 72)]
     c += [f'"v{i}"' for i in range(0, 128)]
     return c
 
 
-def emit_ring(variant, name):
-    s = [f"// GENERATED by tools/gen_gemm_a4.py (ring variant {variant}) - do not edit.",
-         f"#define {name}_FIRST(ABASE, BBASE, M0BASE, OA, OB) \\", "  asm volatile( \\"]
-    for ln in ring_first():
+def emit_pers(variant, name):
+    s = [f"// GENERATED by tools/gen_gemm_a4.py (persistent variant {variant}) - do not edit.",
+         f"#define {name}_FIRST(ABASE, BBASE, M0ST, OA03, OA47, OB03, OB47) \\", "  asm volatile( \\"]
+    for ln in pers_first():
         s.append(f'    "{ln}\\n\\t" \\')
     s.append("    : \\")
-    s.append('    : [abase] "s"(ABASE), [bbase] "s"(BBASE), [m0base] "s"(M0BASE), "{v[128:131]}"(OA), "{v[132:135]}"(OB) \\')
+    s.append('    : [abase] "s"(ABASE), [bbase] "s"(BBASE), [m0st] "s"(M0ST), "{v[128:131]}"(OA03), "{v[132:135]}"(OA47), "{v[136:139]}"(OB03), "{v[140:143]}"(OB47) \\')
     s.append('    : "memory", "scc", "s60", "s61", "s62", "s63", "s65")')
     s.append("")
-    s += [f"#define {name}_TILE(ACC, ABASE, BBASE, NABASE, NBBASE, NITER, M0BASE, OA, OB, NOA, NOB, LADDR) \\", "  asm volatile( \\"]
-    for ln in ring_tile(variant):
+    s += [f"#define {name}_TILE(ACC, ABASE, BBASE, NABASE, NBBASE, NITER, M0ST, W0, W1, OA03, OA47, OB03, OB47, NOA03, NOA47, NOB03, NOB47, LADDR) \\",
+          "  asm volatile( \\"]
+    for ln in pers_tile(variant):
         s.append(f'    "{ln}\\n\\t" \\')
-    outs = [f'"={{a[{4 * i}:{4 * i + 3}]}}"(ACC[{i}])' for i in range(64)]
+    outs = [f'"={{a[{4 * i}:{4 * i + 3}]}}"(ACC[{i}])' for i in range(64)] + ['"+{v[144:147]}"(LADDR)', '[m0out] "=s"(M0ST)']
     s.append("    : " + ", ".join(outs) + " \\")
-    ops = ['[abase] "s"(ABASE)', '[bbase] "s"(BBASE)', '[nabase] "s"(NABASE)', '[nbbase] "s"(NBBASE)', '[niter] "s"(NITER)', '[m0base] "s"(M0BASE)',
-           '"{v[128:131]}"(OA)', '"{v[132:135]}"(OB)', '"{v[136:139]}"(NOA)', '"{v[140:143]}"(NOB)', '"{v[144:147]}"(LADDR)']
+    ops = ['[abase] "s"(ABASE)', '[bbase] "s"(BBASE)', '[nabase] "s"(NABASE)', '[nbbase] "s"(NBBASE)', '[niter] "s"(NITER)', '[m0st] "s"(M0ST)',
+           '[w0] "s"(W0)', '[w1] "s"(W1)',
+           '"{v[128:131]}"(OA03)', '"{v[132:135]}"(OA47)', '"{v[136:139]}"(OB03)', '"{v[140:143]}"(OB47)',
+           '"{v[148:151]}"(NOA03)', '"{v[152:155]}"(NOA47)', '"{v[156:159]}"(NOB03)', '"{v[160:163]}"(NOB47)']
     s.append("    : " + ", ".join(ops) + " \\")
-    s.append("    : " + ", ".join(ring_clobbers()) + ")")
+    s.append("    : " + ", ".join(pers_clobbers()) + ")")
     return "\n".join(s) + "\n"
 
 
-RING_VARIANTS = {
+PERS_VARIANTS = {"GEMM_A4P": {"order": "mt_outer"}}
+
+VARIANTS = {
     "GEMM_A4R": {"order": "mt_outer", "read_gap0": 2, "read_stride": 2, "dma_gap0": 4, "dma_stride": 7},
 }
 
 VARIANTS = {
     "GEMM_A4_KLOOP": {"order": "mt_outer", "dma_spread": 4},
-    "GEMM_A4_KLOOP_V2": {"order": "mt_outer", "dma_spread": 2},
 }
 
 if __name__ == "__main__":
-    txt = "".join(emit(v, n) + "\n" for n, v in VARIANTS.items()) + "".join(emit_ring(v, n) + "\n" for n, v in RING_VARIANTS.items())
+    txt = "".join(emit(v, n) + "\n" for n, v in VARIANTS.items()) + "".join(emit_pers(v, n) + "\n" for n, v in PERS_VARIANTS.items())
     open(OUT, "w").write(txt)
     print(f"wrote {OUT}: {len(txt.splitlines())} lines")

@@ -35,7 +35,7 @@ def ours(M, N, K, akc, bkc, split):
     B = torch.randn((N, K) if bkc else (K, N), device="cuda", generator=g).bfloat16()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     best, bestcfg = 1e9, None
-    for cfg in (1, 2, 3, 4, 5, 7, 8, 9):
+    for cfg in (1, 2, 3, 4, 5, 7, 8, 10):
         for sk in ((1,) if not split else (4, 6, 8, 12)):
             d = GemmDesc()
             d.A, d.B, d.a_kcontig, d.b_kcontig, d.lda, d.ldb = A.data_ptr(), B.data_ptr(), akc, bkc, A.stride(0), B.stride(0)
