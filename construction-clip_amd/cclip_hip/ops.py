@@ -94,7 +94,32 @@ class GemmDesc(ctypes.Structure):
 # With a complete table a run is launch-for-launch reproducible: no trial launches, no timing-dependent choices.
 # AUTOTUNE=False pins configuration 1.
 AUTOTUNE = True
-_TUNED = {}
+
+
+class _GenDict(dict):
+    """dict that counts its mutations (the per-family index of _nearest_tuned is rebuilt when the count moves)"""
+    gen = 0
+
+    def _bump(self):
+        self.gen += 1
+
+    def __setitem__(self, k, v):
+        self._bump(); dict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._bump(); dict.__delitem__(self, k)
+
+    def clear(self):
+        self._bump(); dict.clear(self)
+
+    def update(self, *a, **kw):
+        self._bump(); dict.update(self, *a, **kw)
+
+    def pop(self, *a):
+        self._bump(); return dict.pop(self, *a)
+
+
+_TUNED = _GenDict()        # timed / persisted entries ONLY (choices derived by _nearest_tuned live in _DERIVED)
 _TUNE_MIN_FLOPS = 2.0 * (1 << 29)
 _TUNE_STATE = {"loaded": False, "source_hash": None, "misses": 0, "path": None}
 
@@ -121,40 +146,86 @@ def kernel_source_hash() -> str:
     return _TUNE_STATE["source_hash"]
 
 
-_DERIVED = set()      # keys filled in by _nearest_tuned: used, never written to the persisted table
+import os as _os
+_CFG_REMAP = {int(a): int(b) for a, b in (kv.split(":") for kv in _os.environ.get("CCLIP_GEMM_REMAP", "").split(",") if kv)}
+class _LRU(dict):
+    """bounded key -> choice cache of derived tile choices (insertion-ordered dict: oldest entry evicted first)"""
+    cap = 1024
+
+    def put(self, k, v):
+        if k in self:
+            dict.pop(self, k)
+        elif len(self) >= self.cap:
+            dict.pop(self, next(iter(self)))
+        dict.__setitem__(self, k, v)
+
+    def update(self, other=()):                     # accepts a dict or an iterable of keys (tests restore a saved key set)
+        for k in other:
+            self.put(k, other[k] if isinstance(other, dict) else None)
+
+
+_DERIVED = _LRU()     # choices filled in by _nearest_tuned for keys the table does not hold: bounded, never persisted, never searched
+_FAMILY = {"gen": -1, "idx": {}}
 
 
 def _key_str(key) -> str:
     return "|".join(str(int(k)) if isinstance(k, bool) else str(k) for k in key)
 
 
-def _nearest_tuned(key: str):
-    """A shape the table does not hold whose only difference from a tuned one is its TOKEN dimension (rows of a forward-layout
-    GEMM, the contraction length of a weight-gradient GEMM) (within 16x) - a last partial batch, a packed text batch whose row
-    count follows the captions' lengths - takes that entry's tile configuration instead of being timed in the middle of the
-    step: deterministic (no timing), no synchronisation.  A weight gradient's split-K count is scaled with the contraction
-    length (same K-tiles per split).  CCLIP_TUNE_EXACT=1 (tools/tune_gemm.sh) disables it: every shape is then timed."""
-    import math, os
+def _family_of(f):
+    """(family key, token field index, token count) of a split key: the family is the key with its TOKEN dimension blanked -
+    rows of a forward-layout GEMM, the contraction length of a weight-gradient GEMM."""
+    tok = 3 if (f[4] == "0" and f[5] == "0") else 1
+    return "|".join(f[:tok] + ["*"] + f[tok + 1:]), tok, int(f[tok])
+
+
+def _family_index():
+    """family key -> (sorted token counts, choices in that order), built from the timed / persisted entries and rebuilt only
+    when _TUNED changed.  A lookup is then one split of the QUERY key and a bisect: it does not grow with the number of keys a
+    run has met (round 2 scanned - and string-split - every table entry per miss and stored derived entries in the same table,
+    so a run with a new packed row count every step slowed down linearly with its length)."""
+    if _FAMILY["gen"] != _TUNED.gen:
+        fam = {}
+        for k, v in _TUNED.items():
+            fk, _, t = _family_of(k.split("|"))
+            fam.setdefault(fk, []).append((t, v))
+        _FAMILY["idx"] = {fk: ([t for t, _ in sorted(lst)], [v for _, v in sorted(lst)]) for fk, lst in fam.items()}
+        _FAMILY["gen"] = _TUNED.gen
+    return _FAMILY["idx"]
+
+
+def _nearest_tuned(key: str, unbounded: bool = False):
+    """A shape the table does not hold whose only difference from a tuned one is its TOKEN dimension (within 16x) - a last partial
+    batch, a packed text batch whose row count follows the captions' lengths - takes that entry's tile configuration instead of
+    being timed in the middle of the step: deterministic (no timing), no synchronisation.  A weight gradient's split-K count is
+    scaled with the contraction length (same K-tiles per split).  `unbounded`: no distance limit (data parallelism: a rank must
+    never time a shape on its own, see gemm_bf16).  CCLIP_TUNE_EXACT=1 (tools/tune_gemm.sh) disables it: every shape is timed."""
+    import bisect, math, os
     if os.environ.get("CCLIP_TUNE_EXACT") == "1":
         return None
-    f = key.split("|")
-    tok = 3 if (f[4] == "0" and f[5] == "0") else 1            # field of the token dimension: K for the (0,0) layout, else M
-    want = int(f[tok])
-    best, best_d = None, math.log(16.0)
-    for k, v in _TUNED.items():
-        g = k.split("|")
-        if len(g) != len(f) or any(a != b for i, (a, b) in enumerate(zip(f, g)) if i != tok):
-            continue
-        d = abs(math.log(int(g[tok]) / want))
-        if d < best_d:
-            best, best_d = (k, v), d
+    fk, tok, want = _family_of(key.split("|"))
+    ent = _family_index().get(fk)
+    if ent is None:
+        return None
+    toks, vals = ent
+    i = bisect.bisect_left(toks, want)
+    best, best_d = None, (float("inf") if unbounded else math.log(16.0))
+    for j in (i - 1, i):
+        if 0 <= j < len(toks):
+            d = abs(math.log(toks[j] / want))
+            if d < best_d:
+                best, best_d = j, d
     if best is None:
         return None
-    (k, (cfg, sp)) = best
-    if cfg == 4 and tok == 1 and want % 256:
-        cfg = 3               # the persistent streaming configuration covers full 256-row tiles only
+    cfg, sp = vals[best]
+    if cfg in (4, 8, 10) and tok == 1:
+        kk = int(key.split("|")[3])
+        if cfg == 4 and want % 256:
+            cfg = 3           # the persistent streaming configuration covers full 256-row tiles only
+        if cfg in (8, 10) and (kk % 64 or kk < 192):
+            cfg = 3           # the hand-scheduled configurations need whole 64-deep K-tiles
     if tok == 3 and sp > 1:
-        sp = max(1, min(sp, round(sp * want / int(k.split("|")[3]))))
+        sp = max(1, min(sp, round(sp * want / toks[best])))
     return (cfg, sp)
 
 
@@ -188,7 +259,7 @@ def save_tuned_table(path=None) -> str:
     path = path or env or default
     blob = {"kernel_source_hash": kernel_source_hash(),
             "note": "GEMM tile configuration per (dtype, M, N, K, layout, epilogue, split) key; written by cclip_hip.ops",
-            "table": {k: list(v) for k, v in sorted(_TUNED.items()) if k not in _DERIVED}}
+            "table": {k: list(v) for k, v in sorted(_TUNED.items())}}
     tmp = f"{path}.tmp{os.getpid()}"
     with open(tmp, "w") as f:
         json.dump(blob, f, indent=0, sort_keys=True)
@@ -206,6 +277,11 @@ def sync_tuned_table(group=None, src: int = 0) -> None:
     dist.broadcast_object_list(box, src=src, group=group)
     _TUNED.clear()
     _TUNED.update(box[0])
+
+
+def _collectives_live() -> bool:
+    import torch.distributed as dist
+    return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def _agree_on_choice(choice):
@@ -351,16 +427,24 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
                         split_k if split_candidates is None else -1, colsum_out is not None, colsum_of_b))
         choice = _TUNED.get(key)
         if choice is None:
-            choice = _nearest_tuned(key)
-            if choice is not None:
-                _TUNED[key] = choice                           # (in memory only: a derived entry is never persisted)
-                _TUNE_STATE["derived"] = _TUNE_STATE.get("derived", 0) + 1
-                _DERIVED.add(key)
+            choice = _DERIVED.get(key)
         if choice is None:
-            cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 7, 8, 10)]
+            dp = _collectives_live()
+            choice = _nearest_tuned(key, unbounded=dp)
+            if choice is None and dp:
+                # data parallelism: a shape only THIS rank meets (its packed row count) must not be timed here - the trial
+                # launches would put a broadcast into one rank's call sequence only.  Deterministic fallback instead.
+                choice = (3 if (a_kcontig and b_kcontig) else 1, split_k if split_candidates is None else split_candidates[0][1])
+            if choice is not None:
+                _DERIVED.put(key, choice)                      # bounded cache; never persisted, never searched
+                _TUNE_STATE["derived"] = _TUNE_STATE.get("derived", 0) + 1
+        if choice is None:
+            cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 7, 8)]
             if split_candidates is None and split_k > 1:
                 d.split_ws = split_ws.data_ptr()
             choice = _autotune(d, key, outs3, cands)
+        if _CFG_REMAP:                                         # measurement aid (CCLIP_GEMM_REMAP="8:3,10:3"): A/B a table entry against another configuration
+            choice = (_CFG_REMAP.get(choice[0], choice[0]), choice[1])
         d.tile_config, d.split_k = choice
         if d.split_k > 1 and split_candidates is not None:
             ws = scratch(d.split_k * (M * N + max(M, N)))
@@ -812,7 +896,7 @@ def embed_scatter_tables(text_i32, V: int, *, rows: int, keep: Optional[torch.Te
 
 
 def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None, seq_stride: Optional[int] = None,
-                      seq_off: int = 0, keep: Optional[torch.Tensor] = None, tables=None) -> None:
+                      seq_off: int = 0, keep: Optional[torch.Tensor] = None, tables=None, scratch=None) -> None:
     """demb[text[r]] += dx[(r // L) * seq_stride + seq_off + r % L] for r < rows (the embedding-table gradient).
     keep: optional bool [rows] - rows known to carry a zero gradient (text positions after EOT) can be dropped up front.
     tables: embed_scatter_tables(text_i32, V, rows=rows, keep=keep) built earlier (same text / keep).
@@ -830,7 +914,11 @@ def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None,
     V, D = demb.shape
     order, st, cend, cidx, rlen = tables if tables is not None else embed_scatter_tables(text_i32, V, rows=rows, keep=keep)
     n = rows
-    partial = torch.empty(n, D, device=text_i32.device, dtype=torch.float32)        # slot per chunk; only multi-chunk runs touch it
+    # one slot per CHUNK (a run of <= 64 equal ids), touched by multi-chunk runs only: at most one chunk per distinct id plus one
+    # per 64 rows.  `scratch(n_floats)` (the stack's grow-only scratch) keeps it out of the allocator: round 2 drew a fresh
+    # [rows, D] fp32 tensor - 161 MB at bs 1024 - per backward pass.
+    slots = min(n, V + n // _SEG_CHUNK + 1)
+    partial = scratch(slots * D) if scratch is not None else torch.empty(slots * D, device=text_i32.device, dtype=torch.float32)
     check(lib.cclip_embed_segsum(_p(order), _p(st), _p(cend), _p(cidx), _p(rlen), c_int(n), _p(dx), c_long(dx.stride(-2)), c_int(D),
                                  _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off), _p(partial), _stream()), "cclip_embed_segsum")
 

@@ -382,7 +382,9 @@ class CLIP(nn.Module):
         # sync per call (the row count sizes every launch); the embedding stays dense - its live rows are gathered in,
         # and their gradients scattered back, by two index copies.
         rowmap = cu = None
-        if self._pack_text_rows() and B > 1 and not torch.cuda.is_current_stream_capturing():
+        # (the packed attention kernels hold one sequence per work-group: head_dim 64, <= 128 positions; other geometries run dense)
+        if (self._pack_text_rows() and B > 1 and st.geo.head_dim == 64 and L <= 128
+                and not torch.cuda.is_current_stream_capturing()):
             live = torch.arange(L, device=dev)[None, :] <= eot[:, None]
             rowmap = live.reshape(-1).nonzero().squeeze(1)                    # packed row -> dense row b*L + t (the sync)
             Mp = int(rowmap.numel())
@@ -417,7 +419,7 @@ class CLIP(nn.Module):
         ops.gemm_f32(pooled, p["text_projection"].data.t(), feat)
         ctx = dict(saved=saved, tok=tok, xo=xo, rows=rows, rows_dense=rows_dense, rowmap=rowmap if cu is not None else None,
                    Mp=x.shape[0], pooled=pooled, stp=stp, B=B, L=L) if train else None
-        if train and ops.SCATTER_DETERMINISTIC:
+        if train and ops.SCATTER_DETERMINISTIC and p["token_embedding.weight"].requires_grad:     # (a frozen table needs no gradient tables)
             # The index tables of the deterministic embedding-gradient sum depend on the token ids only: built NOW on a helper
             # stream (under the forward pass's GEMMs) instead of at the end of the backward pass, where their ~25 small
             # launches were 1.2 ms of the step's critical path.
@@ -481,11 +483,11 @@ class CLIP(nn.Module):
             cur.wait_event(c["scatter_ready"])
             for t in c["scatter_tables"]:
                 t.record_stream(cur)               # allocated on the helper stream, consumed here
-            ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, tables=c["scatter_tables"])
+            ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, tables=c["scatter_tables"], scratch=sc.floats)
         else:
             # positions after a row's EOT carry an exactly-zero gradient (causal tower, EOT pooling): drop them from the row list
             keep = (torch.arange(L, device=dev, dtype=torch.int32)[None, :] <= (c["rows_dense"] - torch.arange(B, device=dev, dtype=torch.int32) * L)[:, None]).reshape(-1)
-            ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, keep=keep)
+            ops.embed_scatter_add(c["tok"].view(-1), dx, g["token_embedding.weight"], rows=M, keep=keep, scratch=sc.floats)
         ar.scale_grads(self._rt["txt_names"], 1.0 / S)
         ar.publish_grads(self._rt["txt_names"])
 
@@ -509,6 +511,9 @@ class CLIP(nn.Module):
             return self._image_forward(image, train=False)[0]
         self._ensure_runtime()
         self._arena.refresh_shadows()                  # once, on the caller's stream, before the fork
+        vis = self._rt["vis"]
+        if vis.fp8 and vis._fp8_weights is None:       # lazily built e4m3 weights: build them HERE, before the lanes fork - lane 1 would
+            vis.quantise_weights_fp8()                 # otherwise read weights lane 0 is still quantising on the other stream
         if streams is None:
             if self._rt.get("lane_streams") is None:
                 self._rt["lane_streams"] = (torch.cuda.Stream(device=image.device), torch.cuda.Stream(device=image.device))

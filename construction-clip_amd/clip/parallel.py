@@ -144,11 +144,16 @@ class GradReducer:
         self._armed = self.active
         self._seen = [set() for _ in self.buckets]
         self._works = [None] * len(self.buckets)
+        self._producers = []                  # every stream a gradient kernel of this backward has been reported on, in first-seen order
+        self.waited = [None] * len(self.buckets)   # per bucket: the streams its all-reduce was ordered behind (tests read this)
         self.fired_early = 0
 
     def _on_grads(self, grad_views, streams) -> None:
         if not self._armed:
             return
+        for st in streams:
+            if not any(st is q or st == q for q in self._producers):
+                self._producers.append(st)
         touched = set()
         for t in grad_views:
             bi = self._bucket_of.get(t.storage_offset())
@@ -161,8 +166,16 @@ class GradReducer:
                 self.fired_early += 1
 
     def _fire(self, bi: int, streams) -> None:
+        """A bucket is cut at parameter boundaries only, so it can hold gradients written on DIFFERENT streams (the tail of the
+        vision tower - s0 and its weight-gradient side stream - and the head of the text tower - s1 and its side stream - when
+        both towers run backward side by side), while the notification that completes it names only the streams of its LAST
+        group.  The collective is therefore ordered behind EVERY stream that has produced gradients since begin(), not just the
+        notifying ones: an event recorded now on a stream covers everything enqueued on it so far, which includes this bucket's
+        kernels (round 2 waited on the notifying streams only - correct by luck of the default layout)."""
         s, e = self.buckets[bi]
         view = self.arena.gflat[s:e]
+        streams = list(self._producers) + [st for st in streams if not any(st is q or st == q for q in self._producers)]
+        self.waited[bi] = tuple(streams)
         if not view.is_cuda:
             self._works[bi] = dist.all_reduce(view, group=self.group, async_op=True)
             return

@@ -4,9 +4,10 @@ semantics (/root/reference/CLIP_prefix_caption/test.py:353-514, application.py:1
 The reference calls `model.gpt(inputs_embeds=generated)` on the whole growing sequence at every step and keeps the last
 position's logits.  Here the prefix is run once (prefill) and every later step feeds ONE token per beam through
 `BlockStack.decode_step` against the cached keys / values; beam reordering gathers the cache.  The selection
-arithmetic on the [beams, V] logits (temperature, softmax-log, length-normalised top-k, nucleus filter) is the
-reference's, restated.  For GPT-2 geometry `generate_beam` runs all of it - decode steps AND selection - inside one persistent
-kernel launch (ClipCaptionModel.beam_search_native); the torch loop below is the same arithmetic and its parity reference.
+rule on the [beams, V] logits (temperature, softmax-log, length-normalised top-k; a nucleus filter that cannot move the
+arg-max) is the reference's.  For GPT-2 geometry `generate_beam` / `generate2` run all of it - decode steps AND selection - inside
+one persistent kernel launch (ClipCaptionModel.beam_search_native); the host-side search below (class _Beams) covers what that
+kernel does not.  The reference's loops themselves are restated only in oracle/caption_oracle.py, the checker.
 
 Not carried over: the attention-map dump that the reference's test.py copy of generate_beam interleaves with decoding
 (`output_attentions=True`, test.py:381-390, `attention_map(...)` :438) - visualisation, SURVEY.md section 8 out of scope.
@@ -42,50 +43,71 @@ def generate_beam(model, tokenizer, beam_size: int = 3, prompt=None, embed=None,
         tokens, seq_lengths, scores = model.beam_search_native(generated, beam_size, entry_length, temperature, stop_token,
                                                                prompt_tokens=tokens)
         return _beam_outputs(tokenizer, tokens, seq_lengths, scores, return_tokens)
-    scores = None
-    seq_lengths = torch.ones(beam_size, device=device)
-    is_stopped = torch.zeros(beam_size, device=device, dtype=torch.bool)
+    # Host-side search (nn.Linear-layout stacks, > 8 beams, CPU stubs in the tests, CCLIP_BEAM_NATIVE=0): one KV-cached decode
+    # step per position, the beam bookkeeping kept in a _Beams record.  Same selection rule as the reference (a stopped beam
+    # may only extend by token 0 at no cost; candidates ranked by total log-probability / length), written as one masked
+    # candidate table per step instead of the reference's in-place edits.
     if embed is not None:
-        generated = embed
+        prefix = embed
     else:
         tokens = torch.tensor(tokenizer.encode(prompt)).unsqueeze(0).to(device)
-        generated = model.gpt.transformer.wte(tokens)
-    cache = None
-    step_in = generated                                   # prefill: the whole prefix; afterwards one token per beam
-    for step in range(entry_length):
-        logits, cache = _step_logits(model, step_in, cache)
-        logits = logits / (temperature if temperature > 0 else 1.0)
-        logits = logits.softmax(-1).log()
-        if scores is None:
-            scores, next_tokens = logits.topk(beam_size, -1)
-            cache = cache.expand(beam_size)
-            next_tokens, scores = next_tokens.permute(1, 0), scores.squeeze(0)
-            if tokens is None:
-                tokens = next_tokens
-            else:
-                tokens = torch.cat((tokens.expand(beam_size, *tokens.shape[1:]), next_tokens), dim=1)
-        else:
-            logits[is_stopped] = -float("inf")
-            logits[is_stopped, 0] = 0
-            scores_sum = scores[:, None] + logits
-            seq_lengths[~is_stopped] += 1
-            scores_sum_average = scores_sum / seq_lengths[:, None]
-            scores_sum_average, next_tokens = scores_sum_average.view(-1).topk(beam_size, -1)
-            next_tokens_source = next_tokens // scores_sum.shape[1]
-            seq_lengths = seq_lengths[next_tokens_source]
-            next_tokens = (next_tokens % scores_sum.shape[1]).unsqueeze(1)
-            tokens = torch.cat((tokens[next_tokens_source], next_tokens), dim=1)
-            cache = cache.reorder(next_tokens_source)
-            scores = scores_sum_average * seq_lengths
-            is_stopped = is_stopped[next_tokens_source]
-        step_in = model.gpt.transformer.wte(next_tokens.squeeze(1)).view(beam_size, 1, -1)
-        is_stopped = is_stopped + next_tokens.eq(stop_token).squeeze(1)
-        # `is_stopped.all()` is a device -> host sync; a stopped beam only ever appends token 0 at score 0 and keeps its length,
-        # so looking every 4th step (and on the last) returns the same texts, lengths and scores while the host runs ahead
-        if (step & 3) == 3 or step == entry_length - 1:
-            if is_stopped.all():
-                break
-    return _beam_outputs(tokenizer, tokens, seq_lengths, scores, return_tokens)
+        prefix = model.gpt.transformer.wte(tokens)
+    inv_t = 1.0 / (temperature if temperature > 0 else 1.0)
+    logp, cache = _step_logits(model, prefix, None)                     # prefill: the whole prefix once
+    logp = (logp * inv_t).softmax(-1).log()                             # (softmax-then-log, as the device kernels do)
+    beams = _Beams.start(logp, beam_size, tokens)
+    cache = cache.expand(beam_size)
+    for step in range(1, entry_length):
+        step_in = model.gpt.transformer.wte(beams.last_token()).view(beam_size, 1, -1)
+        logp, cache = _step_logits(model, step_in, cache)
+        logp = (logp * inv_t).softmax(-1).log()
+        parent = beams.extend(logp, stop_token)
+        cache = cache.reorder(parent)
+        # `all stopped` is a device -> host sync; a stopped beam only ever appends token 0 at score 0 and keeps its length, so
+        # looking every 4th step (and on the last) returns the same texts, lengths and scores while the host runs ahead
+        if ((step & 3) == 3 or step == entry_length - 1) and bool((beams.stopped | beams.last_token().eq(stop_token)).all()):
+            break
+    return _beam_outputs(tokenizer, beams.tokens, beams.lengths, beams.total, return_tokens)
+
+
+class _Beams:
+    """Beam bookkeeping of the host-side search: token rows, lengths (floats, as the scores divide by them), total
+    log-probabilities and the stopped flags, all [beams]-shaped device tensors."""
+
+    def __init__(self, tokens, lengths, total, stopped):
+        self.tokens, self.lengths, self.total, self.stopped = tokens, lengths, total, stopped
+
+    @classmethod
+    def start(cls, logp, k: int, prompt_tokens):
+        """first position: the k most probable tokens of the single prefix row open the beams"""
+        total, first = logp[0].topk(k)
+        col = first.unsqueeze(1)
+        toks = col if prompt_tokens is None else torch.cat((prompt_tokens.expand(k, -1), col), dim=1)
+        b = cls(toks, torch.ones(k, device=logp.device), total, torch.zeros(k, dtype=torch.bool, device=logp.device))
+        return b
+
+    def last_token(self):
+        return self.tokens[:, -1]
+
+    def extend(self, logp, stop_token: int):
+        """one position further: returns each new beam's parent row (for the KV-cache reorder)"""
+        k, V = logp.shape
+        # a beam stops on the position AFTER it emitted the stop token
+        self.stopped = self.stopped | self.tokens[:, -1].eq(stop_token)
+        live = ~self.stopped
+        # candidate table: live rows extend by any token; a stopped row offers only token 0, free of charge
+        step_cost = torch.where(live[:, None], logp, torch.full_like(logp, -float("inf")))
+        step_cost[self.stopped, 0] = 0.0
+        new_len = self.lengths + live.to(self.lengths.dtype)
+        ranked = (self.total[:, None] + step_cost) / new_len[:, None]
+        best, flat = ranked.reshape(-1).topk(k)
+        parent = torch.div(flat, V, rounding_mode="floor")
+        token = flat - parent * V
+        self.lengths = new_len[parent]
+        self.total = best * self.lengths
+        self.stopped = self.stopped[parent]
+        self.tokens = torch.cat((self.tokens[parent], token.unsqueeze(1)), dim=1)
+        return parent
 
 
 def _beam_outputs(tokenizer, tokens, seq_lengths, scores, return_tokens: bool):
@@ -127,21 +149,16 @@ def generate2(model, tokenizer, tokens=None, prompt=None, embed=None, entry_coun
             out_tokens = new_tokens if embed is None or prev is None else torch.cat((prev.to(new_tokens.device), new_tokens), dim=1)
             generated_list.append(tokenizer.decode(list(out_tokens.squeeze(0).cpu().numpy())))
             continue
+        # host-side loop (stacks the persistent kernel does not cover, CPU stubs): the same observation makes the sort / cumulative
+        # sum of the nucleus filter unnecessary for the arg-max - one KV-cached step and one arg-max per position
         cache = None
         for _ in range(entry_length):
             logits, cache = _step_logits(model, step_in, cache)
-            logits = logits / (temperature if temperature > 0 else 1.0)
-            sorted_logits, sorted_indices = torch.sort(logits, descending=True)
-            cumulative_probs = torch.cumsum(torch.softmax(sorted_logits, dim=-1), dim=-1)
-            remove = cumulative_probs > top_p
-            remove[..., 1:] = remove[..., :-1].clone()
-            remove[..., 0] = 0
-            logits[:, sorted_indices[remove]] = -float("inf")
-            next_token = torch.argmax(logits, -1).unsqueeze(0)
-            out_tokens = next_token if out_tokens is None else torch.cat((out_tokens, next_token), dim=1)
-            step_in = model.gpt.transformer.wte(next_token)
-            if stop_token == next_token.item():
+            pick = logits.argmax(dim=-1, keepdim=True)                  # [1, 1]; the temperature does not move an arg-max
+            out_tokens = pick if out_tokens is None else torch.cat((out_tokens, pick), dim=1)
+            if int(pick) == stop_token:
                 break
+            step_in = model.gpt.transformer.wte(pick)
         generated_list.append(tokenizer.decode(list(out_tokens.squeeze(0).cpu().numpy())))
     if return_tokens:
         return generated_list[0], out_tokens

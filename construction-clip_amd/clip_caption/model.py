@@ -835,7 +835,7 @@ class ClipCaptionModel(nn.Module):
                 cur.wait_event(c["scatter_ready"])
                 for t in tables:
                     t.record_stream(cur)
-            ops.embed_scatter_add(c["ids"].view(-1), dx, g[wte_name], rows=B * Lt, L=Lt, seq_stride=S, seq_off=P, tables=tables)
+            ops.embed_scatter_add(c["ids"].view(-1), dx, g[wte_name], rows=B * Lt, L=Lt, seq_stride=S, seq_off=P, tables=tables, scratch=sc.floats)
         # mapper: d prefix_proj = dx[b, :P]  -> a [B, P*D] matrix with row stride S*D inside dx / dxb
         if self._mstack is not None:
             if p["clip_project.linear.weight"].requires_grad:

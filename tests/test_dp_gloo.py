@@ -101,7 +101,34 @@ def _worker(rank, world, port, out_dir):
         assert a3.params["logit_scale"].grad.data_ptr() == a3.g["logit_scale"].data_ptr()
         opt.step(grad_scale=0.5, pending=pend)
     overlap_ok = torch.equal(a3.flat, res[0]) and min(early) >= 1
-    torch.save(dict(loss=loss.detach(), stats=stats, dfi=fi.grad, dft=ft.grad, dls=lsp.grad, gsum_ok=gsum_ok, async_ok=async_ok, overlap_ok=overlap_ok, early=early),
+    # a bucket that STRADDLES the two towers (buckets are cut at parameter boundaries only): its all-reduce must be ordered behind
+    # the streams of BOTH towers' gradient kernels, whichever notification completes it (round-2 advisory finding)
+    names = [n for n in a3.names if a3.params[n].requires_grad and n != "logit_scale"]
+    order = sorted(names, key=lambda n: a3.offsets[n])
+    vis_last = max(i for i, n in enumerate(order) if n.startswith("visual."))
+    straddle_ok = False
+    if vis_last + 1 < len(order):
+        lo, hi = a3.offsets[order[vis_last]], a3.offsets[order[vis_last + 1]]
+        for cap in (200_000, 120_000, 80_000, 50_000, 30_000):
+            red2 = par.GradReducer(a3, max_bucket_elems=cap)
+            bi = [i for i, (s_, e_) in enumerate(red2.buckets) if s_ <= lo < e_ and s_ <= hi < e_]
+            if not bi:
+                continue
+            bi = bi[0]
+            red2.begin()
+            s_, e_ = red2.buckets[bi]
+            in_b = [n for n in order if s_ <= a3.offsets[n] < e_]
+            vis = [n for n in in_b if n.startswith("visual.")]
+            txt = [n for n in in_b if not n.startswith("visual.")]
+            a3.notify_grads([a3.g[n] for n in vis], ("s0", "w0"))          # vision tower: its stream and weight-gradient side stream
+            assert red2.waited[bi] is None
+            a3.notify_grads([a3.g[n] for n in txt], ("s1", "w1"))          # the text tower's notification completes the bucket
+            straddle_ok = red2.waited[bi] is not None and set(red2.waited[bi]) >= {"s0", "w0", "s1", "w1"}
+            red2._works[bi].wait()
+            red2._armed = False
+            break
+    a3.grad_listener = red._on_grads
+    torch.save(dict(loss=loss.detach(), stats=stats, dfi=fi.grad, dft=ft.grad, dls=lsp.grad, gsum_ok=gsum_ok, async_ok=async_ok, overlap_ok=overlap_ok, early=early, straddle_ok=straddle_ok),
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -130,6 +157,7 @@ def test_dp_contrastive_matches_single_process(tmp_path):
         assert torch.allclose(o["dft"], ft.grad[r * nloc:(r + 1) * nloc], atol=1e-6)
         assert o["gsum_ok"]
         assert o["async_ok"]                                         # bucket-wise AdamW under async all-reduce == one pass
+        assert o["straddle_ok"]                                      # a two-tower bucket waits for both towers' streams
         assert o["overlap_ok"], o["early"]                           # buckets reduced from inside backward == the same
     assert abs(dls.item() - ls.grad.item()) < 1e-6
 

@@ -218,3 +218,44 @@ def test_gemm_tile_lookup_takes_the_nearest_token_count(monkeypatch):
     finally:
         ops._TUNED.clear(); ops._TUNED.update(saved)
         ops._DERIVED.clear(); ops._DERIVED.update(saved_d)
+
+
+def test_gemm_tile_lookup_stays_flat_over_many_row_counts():
+    """A run that meets a new packed row count every step (shuffled captions) must not grow the tuned table nor slow its lookups
+    down: derived choices live in a bounded cache, the table holds timed / persisted entries only, and the nearest-token search is
+    a bisect over a per-family index (no scan, no string split per table entry)."""
+    import time
+    from cclip_hip import ops
+    saved, saved_d = dict(ops._TUNED), dict(ops._DERIVED)
+    try:
+        ops._TUNED.clear(); ops._DERIVED.clear()
+        fams = []
+        for n, k in ((1536, 512), (512, 512), (2048, 512), (512, 2048), (2304, 768), (768, 768), (3072, 768), (768, 3072)):
+            fam = f"bfloat16|%d|{n}|{k}|1|1|0|0|1|0|0|1|1|0|0"
+            fams.append(fam)
+            for m in (20000, 40311, 78848):
+                ops._TUNED[fam % m] = (8, 1)
+        base = len(ops._TUNED)
+
+        def lookups(ms):
+            t0 = time.perf_counter()
+            for m in ms:
+                for fam in fams:
+                    key = fam % m
+                    c = ops._TUNED.get(key) or ops._DERIVED.get(key)
+                    if c is None:
+                        c = ops._nearest_tuned(key)
+                        assert c == (8, 1)
+                        ops._DERIVED.put(key, c)
+            return (time.perf_counter() - t0) / (len(ms) * len(fams))
+
+        first = lookups(range(30000, 31000))
+        lookups(range(31000, 39000))
+        last = lookups(range(39000, 40000))                       # 10 000 distinct row counts x 8 families later
+        assert len(ops._TUNED) == base                            # the table did not grow
+        assert len(ops._DERIVED) <= ops._DERIVED.cap              # the derived cache is bounded
+        assert last < 3 * first + 2e-5, (first, last)             # per-call cost is flat (it was linear in the keys met)
+        assert last < 2e-4
+    finally:
+        ops._TUNED.clear(); ops._TUNED.update(saved)
+        ops._DERIVED.clear(); ops._DERIVED.update(saved_d)
