@@ -77,6 +77,7 @@ class GemmDesc(ctypes.Structure):
         ("split_k", c_int), ("split_ws", c_void_p),
         ("tile_config", c_int),
         ("colsum_out", c_void_p), ("colsum_accumulate", c_int), ("colsum_of_b", c_int),
+        ("ln_stats", c_void_p), ("ln_c1", c_void_p), ("rowstats_out", c_void_p),
     ]
 
 
@@ -369,13 +370,16 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
               out_pre: Optional[torch.Tensor] = None, split_k: int = 1,
               split_ws: Optional[torch.Tensor] = None, M: Optional[int] = None, tile_config: int = 0,
               split_candidates=None, scratch=None, colsum_out: Optional[torch.Tensor] = None,
-              colsum_accumulate: bool = False, colsum_of_b: bool = False) -> None:
+              colsum_accumulate: bool = False, colsum_of_b: bool = False, ln_stats: Optional[torch.Tensor] = None,
+              ln_c1: Optional[torch.Tensor] = None, rowstats_out: Optional[torch.Tensor] = None) -> None:
     """C[m][n] = epi(alpha * sum_k A(m,k) B(n,k)); see cclip_gemm_bf16 in include/cclip_hip.h.
     A: [M,K] (a_kcontig) or [K,M]; B: [N,K] (b_kcontig) or [K,N]; 2-D, inner stride 1.
     split_candidates (wgrad): list of (tile_config, split_k) to autotune over; `scratch(n)` returns an fp32
     workspace of n floats for the chosen split.
     colsum_out (wgrad layout only): fp32 [M] (+)= sum_k A(m,k), or with colsum_of_b fp32 [N] (+)= sum_k B(n,k) - the bias
-    gradient, fused into the weight-gradient GEMM."""
+    gradient, fused into the weight-gradient GEMM.
+    ln_stats [M, 2] + ln_c1 [N]: LayerNorm folded into this projection; rowstats_out [N/64, M, 2]: the residual form also emits
+    the 16-bit copy (out_bf16) and row statistics for the next folded projection (include/cclip_hip.h; tile configuration 8)."""
     _req16(A, "A"); _req16(B, "B")
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
     Mx, K = (A.shape[0], A.shape[1]) if a_kcontig else (A.shape[1], A.shape[0])
@@ -413,6 +417,15 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
         _req(colsum_out, torch.float32, "colsum_out")
         assert not a_kcontig and not b_kcontig and colsum_out.numel() == (N if colsum_of_b else M) and colsum_out.is_contiguous()
         d.colsum_out, d.colsum_accumulate, d.colsum_of_b = colsum_out.data_ptr(), int(colsum_accumulate), int(colsum_of_b)
+    if ln_stats is not None or rowstats_out is not None:
+        for t_, n_ in ((ln_stats, "ln_stats"), (ln_c1, "ln_c1"), (rowstats_out, "rowstats_out")):
+            if t_ is not None:
+                _req(t_, torch.float32, n_)
+                assert t_.is_contiguous()
+        d.ln_stats = 0 if ln_stats is None else ln_stats.data_ptr()
+        d.ln_c1 = 0 if ln_c1 is None else ln_c1.data_ptr()
+        d.rowstats_out = 0 if rowstats_out is None else rowstats_out.data_ptr()
+        d.tile_config = tile_config = 8           # the only configuration with these epilogue forms
     if bias is not None:
         _req(bias, torch.float32, "bias")
     if residual is not None:
@@ -459,6 +472,13 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
         GEMM_EVENTS.append((e0, e1, 2.0 * M * N * K, (int(a_kcontig), int(b_kcontig)), (M, N, K)))
         return
     _launch_gemm(d)
+
+
+def rowstats_combine(partials: torch.Tensor, stats: torch.Tensor, *, rows: int, D: int, eps: float = 1e-5) -> None:
+    """stats[m] = (mean, rstd) from the [nblk, rows, 2] (sum, sum of squares) partials a residual GEMM emitted (rowstats_out)"""
+    _req(partials, torch.float32, "partials"); _req(stats, torch.float32, "stats")
+    check(lib.cclip_rowstats_combine(_p(partials), c_int(partials.shape[0]), c_int(rows), c_int(D), c_float(eps), _p(stats), _stream()),
+          "cclip_rowstats_combine")
 
 
 # --------------------------------------------------------------------------------------------

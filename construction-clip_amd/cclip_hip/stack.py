@@ -102,6 +102,33 @@ class BlockStack:
         # quantised by one extra pass, the MLP hidden leaves the fc GEMM's epilogue as e4m3 + block scales directly)
         self.fp8_wide = True
         self._fp8_weights = None
+        # inference: LayerNorm folded into the projection behind it (forward(), `fold`); the gamma-scaled weight copies and their
+        # column sums are rebuilt when `weights_version` (the arena's parameter stamp) moves
+        self._fold_w = None
+        self._fold_version = None
+
+    def fold_enabled(self) -> bool:
+        import os
+        return os.environ.get("CCLIP_LN_FOLD", "1") != "0" and self.geo.linear_layout and not self.fp8
+
+    def _fold_weights(self, version):
+        """Per block: W' = gamma (.) W as 16-bit operands, c1 = row sums of W' (fp32, of the ROUNDED values: the folded epilogue's
+        `mean * c1` then removes exactly the mean term the MFMAs added), c2 = b + W beta.  ln_1 -> qkv, ln_2 -> fc."""
+        if self._fold_w is None or self._fold_version != version:
+            out = []
+            for w in self.blocks:
+                ent = {}
+                for tag, wm, bias, gam, bet in (("q", w.w_qkv, w.b_qkv, w.ln1_w, w.ln1_b), ("f", w.w_fc, w.b_fc, w.ln2_w, w.ln2_b)):
+                    wf = wm.float()
+                    ws = (wf * gam.float()[None, :]).to(wm.dtype).contiguous()
+                    c1 = ws.float().sum(dim=1).contiguous()
+                    c2 = (wf @ bet.float()).contiguous()
+                    if bias is not None:
+                        c2 = (c2 + bias.float()).contiguous()
+                    ent[tag] = (ws, c1, c2)
+                out.append(ent)
+            self._fold_w, self._fold_version = out, version
+        return self._fold_w
 
     def quantise_weights_fp8(self) -> None:
         """(Re)build the e4m3 copies + per-channel scales of every block's qkv / fc weights from the 16-bit shadows."""
@@ -136,7 +163,8 @@ class BlockStack:
 
     def forward(self, x: torch.Tensor, B: int, *, saved: Optional[dict] = None,
                 key_keep: Optional[torch.Tensor] = None, T: Optional[int] = None, kv_out=None,
-                cu: Optional[torch.Tensor] = None, tail_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+                cu: Optional[torch.Tensor] = None, tail_rows: Optional[torch.Tensor] = None,
+                weights_version=None) -> torch.Tensor:
         """x: fp32 [B*T, D] residual stream entering block 0; returns the stream leaving the last block.
         saved=None (inference) keeps nothing and updates x in place; otherwise x must be saved["xs"][0,0].
         kv_out = (kcache, vcache), each [L, B, Smax, D] 16-bit: every layer's keys / values of positions [0, T) are
@@ -165,6 +193,23 @@ class BlockStack:
             saved["tail"] = None
         else:
             bf = torch.empty(M, 6 * D + Hd, device=dev, dtype=self.dtype)  # xn | qkv | a | - | g  (reused per layer)
+        # INFERENCE, LayerNorm folded away (SURVEY 2b "LayerNorm ... fused into the following GEMM"): the residual-writing GEMMs
+        # (out-proj, c_proj) also emit a 16-bit copy of the new stream rows and per-row (sum, sum of squares) partials; the next
+        # projection (fc, qkv of the next block) multiplies the RAW rows by W' = gamma (.) W and applies mean / rstd in its epilogue:
+        # LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (W beta + b).  24 of a ViT-B/32 tower's 25 standalone LayerNorm passes
+        # (a read of the fp32 stream + a 16-bit write each) disappear; block 0's ln_1 and the pooled final LayerNorm stay.
+        # Needs whole 256-row / 256-column tiles (tile configuration 8); CCLIP_LN_FOLD=0 switches it off.
+        import os
+        fold = (not train and weights_version is not None and kc and cu is None and kv_out is None and not self.fp8
+                and os.environ.get("CCLIP_LN_FOLD", "1") != "0" and geo.head_dim == 64 and geo.act in (ops.ACT_NONE, ops.ACT_QUICKGELU)
+                and M % 256 == 0 and D % 256 == 0 and Hd % 256 == 0 and D >= 128)
+        if fold:
+            fw = self._fold_weights(weights_version)
+            nblk = D // 64
+            part = torch.empty(nblk * M * 2 + M * 2, device=dev, dtype=torch.float32)     # (per call: lanes run this stack concurrently)
+            partials, stats = part[:nblk * M * 2].view(nblk, M, 2), part[nblk * M * 2:].view(M, 2)
+            xb = torch.empty(M, D, device=dev, dtype=self.dtype)   # 16-bit copy of the current stream rows (same row stride as the fp32 stream: one ldc per GEMM)
+        have_stats = False                                     # stats / xb describe the CURRENT x_in (ln_1's input)?
         for l, w in enumerate(self.blocks):
             if train:
                 row = bf[l]
@@ -194,6 +239,9 @@ class BlockStack:
                 wq8, swq = self._fp8_weights[l]["w_qkv"]
                 ops.layernorm_fwd_fp8(x_in, w.ln1_w, w.ln1_b, x8, sx, rows=M)
                 ops.gemm_fp8(x8, sx, wq8, swq, qkv, bias=w.b_qkv, M=M)
+            elif fold and have_stats:
+                wsq, c1q, c2q = fw[l]["q"]
+                ops.gemm_bf16(xb, wsq, bias=c2q, out_bf16=qkv, M=M, ln_stats=stats, ln_c1=c1q)
             else:
                 ops.layernorm_fwd(x_in, w.ln1_w, w.ln1_b, rows=M, out_bf16=xn1, mean=m1, rstd=r1)
                 ops.gemm_bf16(xn1, w.w_qkv, b_kcontig=kc, bias=w.b_qkv, out_bf16=qkv, M=M)
@@ -230,6 +278,9 @@ class BlockStack:
                 if not a_mx:
                     ops.quantize_mx_fp8(a, x8, xmx, rows=M)
                 ops.gemm_fp8(x8, None, wo8, swo, bias=w.b_o, M=M, block_scale_a=xmx, out_f32=x_mid, residual=x_in, half=self.dtype)
+            elif fold:
+                ops.gemm_bf16(a, w.w_o, bias=w.b_o, residual=x_in, out_f32=x_mid, out_bf16=xb, M=M, rowstats_out=partials)
+                ops.rowstats_combine(partials, stats, rows=M, D=D)
             else:
                 ops.gemm_bf16(a, w.w_o, b_kcontig=kc, bias=w.b_o, residual=x_in, out_f32=x_mid, M=M)
             if f8 and geo.act in (ops.ACT_NONE, ops.ACT_QUICKGELU):
@@ -239,12 +290,19 @@ class BlockStack:
                     ops.gemm_fp8(x8, sx, wf8, swf, bias=w.b_fc, act=geo.act, M=M, out_mx=(g8, gmx), half=self.dtype)
                 else:
                     ops.gemm_fp8(x8, sx, wf8, swf, g, bias=w.b_fc, act=geo.act, M=M)
+            elif fold:
+                wsf, c1f, c2f = fw[l]["f"]
+                ops.gemm_bf16(xb, wsf, bias=c2f, act=geo.act, out_bf16=g, M=M, ln_stats=stats, ln_c1=c1f)
             else:
                 ops.layernorm_fwd(x_mid, w.ln2_w, w.ln2_b, rows=M, out_bf16=xn2, mean=m2, rstd=r2)
                 ops.gemm_bf16(xn2, w.w_fc, b_kcontig=kc, bias=w.b_fc, act=geo.act, out_bf16=g, out_pre=h, M=M)
             if f8 and wide:
                 wp8, swp = self._fp8_weights[l]["w_proj"]
                 ops.gemm_fp8(g8, None, wp8, swp, bias=w.b_proj, M=M, block_scale_a=gmx, out_f32=x_out, residual=x_mid, half=self.dtype)
+            elif fold and l + 1 < L:
+                ops.gemm_bf16(g, w.w_proj, bias=w.b_proj, residual=x_mid, out_f32=x_out, out_bf16=xb, M=M, rowstats_out=partials)
+                ops.rowstats_combine(partials, stats, rows=M, D=D)
+                have_stats = True
             else:
                 ops.gemm_bf16(g, w.w_proj, b_kcontig=kc, bias=w.b_proj, residual=x_mid, out_f32=x_out, M=M)
             x = x_out

@@ -288,7 +288,8 @@ class CLIP(nn.Module):
                          mean=st0[0] if train else None, rstd=st0[1] if train else None)
         rows = (torch.arange(B, device=dev, dtype=torch.int32) * T).contiguous()
         tail = self._tail_rows()
-        xo = st.forward(x, B, saved=saved, tail_rows=rows.long() if tail else None)     # tail: [B, D], the class rows only
+        xo = st.forward(x, B, saved=saved, tail_rows=rows.long() if tail else None,     # tail: [B, D], the class rows only
+                        weights_version=ar._stamp)
         if tail:
             rows = None
         pooled = torch.empty(B, D, device=dev, dtype=torch.float32)
@@ -512,6 +513,8 @@ class CLIP(nn.Module):
         self._ensure_runtime()
         self._arena.refresh_shadows()                  # once, on the caller's stream, before the fork
         vis = self._rt["vis"]
+        if vis.fold_enabled():
+            vis._fold_weights(self._arena._stamp)      # (the folded-LayerNorm weight copies too: built here, not inside a lane)
         if vis.fp8 and vis._fp8_weights is None:       # lazily built e4m3 weights: build them HERE, before the lanes fork - lane 1 would
             vis.quantise_weights_fp8()                 # otherwise read weights lane 0 is still quantising on the other stream
         if streams is None:

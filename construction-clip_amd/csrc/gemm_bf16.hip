@@ -99,8 +99,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+
+#ifndef CCLIP_F16
+// (mean, rstd) of every row from its per-64-column (sum, sum of squares) partials (cclip_rowstats_combine): one thread per row,
+// partials added in block order (deterministic)
+__global__ __launch_bounds__(256) void rowstats_combine_kernel(const float* __restrict__ part, int nblk, int rows, int D, float eps,
+                                                               float* __restrict__ stats) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= rows) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = 0; j < nblk; ++j) {
+    const float2 v = *(const float2*)(part + ((long)j * rows + m) * 2);
+    s1 += v.x; s2 += v.y;
+  }
+  const float mean = s1 / (float)D;
+  const float var = fmaxf(s2 / (float)D - mean * mean, 0.f);
+  *(float2*)(stats + (long)m * 2) = make_float2(mean, rsqrtf(var + eps));
+}
+#endif
 }  // namespace CCLIP_NS
 using namespace CCLIP_NS;
+
+#ifndef CCLIP_F16
+extern "C" int cclip_rowstats_combine(const float* partials, int32_t nblk, int32_t rows, int32_t D, float eps, float* stats, hipStream_t stream) {
+  if (!partials || !stats || nblk <= 0 || rows <= 0 || D <= 0) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(rowstats_combine_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, partials, nblk, rows, D, eps, stats);
+  return cclip_launch_status();
+}
+#endif
 
 
 extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
@@ -135,7 +161,14 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   }
 
   { static const int dbg = getenv("CCLIP_GEMM_DBG") ? atoi(getenv("CCLIP_GEMM_DBG")) : 0; a.dbg = dbg; }
+  a.ln_stats = d->ln_stats; a.ln_c1 = d->ln_c1; a.rowstats = d->rowstats_out;
   int cfg = d->tile_config;
+  if (a.ln_stats || a.ln_c1 || a.rowstats) {        // the folded-LayerNorm forms: configuration 8, whole 256x256 tiles only
+    if (cfg != 8 || (d->M & 255) || (d->N & 255) || splits > 1 || !d->a_kcontig || !d->b_kcontig) return CCLIP_ERR_ARG;
+    if ((a.ln_stats == nullptr) != (a.ln_c1 == nullptr)) return CCLIP_ERR_ARG;
+    if (a.ln_stats && !(d->out_bf16 && !d->out_f32 && !d->residual && !d->out_pre_bf16 && d->act < CCLIP_ACT_DQUICKGELU)) return CCLIP_ERR_ARG;
+    if (a.rowstats && !(d->out_f32 && d->residual && d->out_bf16 && !d->out_pre_bf16 && d->act == CCLIP_ACT_NONE && d->ldr == d->ldc)) return CCLIP_ERR_ARG;
+  }
   // M <= 8 against K-strided weights (the projections of a KV-cached decode step): weight-read-bound GEMV path
   if (cfg == 0 && splits == 1 && d->M <= 8 && !d->colsum_out && cclip_gemm_launch_skinny(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a))
     return cclip_launch_status();

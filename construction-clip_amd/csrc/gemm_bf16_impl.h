@@ -32,6 +32,9 @@ struct GemmArgs {
   // with split-K the raw partials go to colsum_ws[z][M] and the combine kernel finishes them
   float* colsum_dst = nullptr; float* colsum_ws = nullptr; int colsum_acc = 0;
   int colsum_b = 0;   // 1: row sums of B (size N) instead - the Conv1D weight layout, where dY is the B operand
+  // configurations 8 / 10: LayerNorm folded into the projection (cclip_hip.h): (mean, rstd) per row, column sums of the scaled weight;
+  // the residual form's extra outputs for the next folded projection
+  const float* ln_stats = nullptr; const float* ln_c1 = nullptr; float* rowstats = nullptr;
   int dbg = 0;        // timing ablations of configurations 8 / 10 (CCLIP_GEMM_DBG; bit 0: no epilogue) - never set by the product path
 };
 

@@ -85,6 +85,12 @@ typedef struct cclip_gemm_desc {
                         *     quantisation option - 9.39 rounds of 0.75-size tiles instead of 7.03 rounds of full ones.
                         * 7 = configuration 3 with the ROTATED K loop (k-step 1 of the previous K-tile is multiplied right after the
                         *     barrier while the new tile's fragments are read) - forward layout only; status 1 otherwise.
+                        * 8 = 256x256 run by FOUR waves of 128x128 (one per SIMD, accumulators in AGPRs) with a hand-scheduled inline-asm
+                        *     K loop (tools/gen_gemm_a4.py) and an LDS-staged epilogue that stores whole 256-byte row segments;
+                        *     forward layout, K % 64 == 0, K >= 128, no split-K; status 1 otherwise.
+                        * 10 = configuration 8 as a persistent kernel (one work-group per CU walks tiles, the next tile's first operands
+                        *     are staged during the current tile's last iteration); K >= 192.  Not an autotuner candidate: next to a
+                        *     second stream's kernels it loses to configuration 8 (it holds every CU for its whole life).
                         * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
   /* wgrad layout (0,0) only: colsum_out[m] (+)= sum_k A(m,k) - the BIAS gradient of the layer whose weight gradient this
    * call computes (A = dY^T), taken off the operand tiles already in LDS by one extra MFMA per m-tile against an all-ones
@@ -93,8 +99,20 @@ typedef struct cclip_gemm_desc {
   int32_t colsum_accumulate;
   int32_t colsum_of_b;   /* 1: colsum_out[n] (+)= sum_k B(n,k) instead (size N; first ROW block of tiles) - the Conv1D weight layout,
                           * where dY is the B operand of the weight-gradient GEMM; workspace split_k*(M*N + max(M,N)) floats */
+  /* ---- LayerNorm FOLDED into the projection that follows it (tile configuration 8; M % 256 == 0, N % 256 == 0) ----
+   * LayerNorm(x) W^T + b  =  rstd_m * ( x W'^T - mean_m * c1_n ) + c2_n   with W' = gamma (.) W, c1_n = sum_k W'(n,k),
+   * c2_n = b_n + sum_k beta_k W(n,k): A holds the UN-normalised rows as 16-bit values, B holds W', `bias` holds c2,
+   * ln_stats = fp32 [M][2] (mean, rstd) of the rows, ln_c1 = fp32 [N].  Epilogue: v = rstd*(alpha*acc - mean*c1) + bias, then act. */
+  const float* ln_stats;
+  const float* ln_c1;
+  /* The residual-stream form (out_f32 = alpha*acc + bias + residual) may emit what the NEXT folded projection needs: out_bf16 (a
+   * 16-bit copy of the new rows; allowed next to out_f32 + residual for these configurations) and rowstats_out = fp32
+   * [N/64][M][2]: (sum, sum of squares) of every new row over each 64-column block, combined by cclip_rowstats_combine. */
+  float* rowstats_out;
 } cclip_gemm_desc;
 int cclip_gemm_bf16(const cclip_gemm_desc* d, hipStream_t stream);
+/* stats[m] = (mean, rstd = rsqrt(var + eps)) of row m from nblk partial (sum, sum of squares) pairs: partials fp32 [nblk][rows][2] */
+int cclip_rowstats_combine(const float* partials, int32_t nblk, int32_t rows, int32_t D, float eps, float* stats, hipStream_t stream);
 
 /* ---- LayerNorm (fp32 statistics, eps as given) ---------------------------------------------
  * Replaces nn.LayerNorm (ln_pre / ln_1 / ln_2 / ln_post / ln_final; GPT-2 ln_1 / ln_2 / ln_f).

@@ -536,3 +536,30 @@ def test_empty_and_single_row_batches():
     model.train()
     with pytest.raises(RuntimeError):
         model.encode_image(img[:0])
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1.2e-2), (torch.float16, 1e-3)])
+def test_inference_layernorm_fold_matches_the_standalone_layernorm_path(dt, tol, monkeypatch):
+    """Inference at batch sizes whose token count fills whole 256-row tiles runs with LayerNorm folded into qkv / fc (BlockStack
+    `fold`).  ViT-B/32 geometry, 128 images (6400 token rows): features against the CPU oracle within the operand type's bound,
+    and as close to it as the standalone-LayerNorm path (CCLIP_LN_FOLD=0) is; arg-max over random prompts unchanged."""
+    import clip
+    from clip.weights import MODELS, init_state_dict, synthetic_images
+    from oracle import clip_oracle as O
+    geo = MODELS["ViT-B/32"]
+    sd = init_state_dict(geo, 567)
+    img = synthetic_images(128, geo, 21)
+    model = clip.build_model(sd, dt).to("cuda:0").eval()
+    with torch.no_grad():
+        monkeypatch.setenv("CCLIP_LN_FOLD", "1")
+        f_fold = model.encode_image(img.cuda()).float().cpu()
+        monkeypatch.setenv("CCLIP_LN_FOLD", "0")
+        f_plain = model.encode_image(img.cuda()).float().cpu()
+        ref = O.encode_image(sd, img[:32])
+    assert not torch.equal(f_fold, f_plain)                       # the folded path really ran
+    rel = lambda a, b: ((a - b).norm(dim=1) / b.norm(dim=1)).max().item()   # noqa: E731
+    e_fold, e_plain = rel(f_fold[:32], ref), rel(f_plain[:32], ref)
+    assert e_fold < tol, (e_fold, e_plain)
+    assert e_fold < 2.0 * e_plain + 1e-4, (e_fold, e_plain)
+    t = torch.randn(9, ref.shape[1])
+    assert torch.equal((f_fold[:32] @ t.t()).argmax(1), (ref @ t.t()).argmax(1)) or (dt == torch.bfloat16)

@@ -387,3 +387,53 @@ def test_wgrad_with_fused_bias_gradient(n_out, k_in, tokens, cfg, split, conv1d)
         _report("fused wgrad", gw, ref_w + (gw0 if accumulate else 0), 2e-3)
         want_b = ref_b + (gb0 if accumulate else 0)
         assert (gb - want_b).abs().max() <= 2e-3 * want_b.abs().max(), (gb - want_b).abs().max()
+
+
+def test_gemm_cfg8_layernorm_fold_and_rowstats():
+    """LayerNorm folded into the projection (include/cclip_hip.h): the residual form emits the 16-bit copy of the new rows and
+    per-64-column (sum, sum of squares) partials; cclip_rowstats_combine turns them into (mean, rstd); the folded projection
+    multiplies the RAW rows by W' = gamma (.) W and applies rstd * (acc - mean * c1) + c2.  Checked against torch fp32 LayerNorm
+    + matmul on the same 16-bit operands."""
+    ops = _ops()
+    M, D, N = 512, 768, 1024
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = (torch.randn(M, D, device="cuda", generator=g) * 0.2).bfloat16()
+    wo = (torch.randn(D, D, device="cuda", generator=g) * 0.05).bfloat16()
+    bo = torch.randn(D, device="cuda", generator=g) * 0.1
+    x0 = torch.randn(M, D, device="cuda", generator=g) * 2.0 + 0.7          # residual stream with a non-zero mean
+    # producer: x = x0 + a wo^T + bo, in place, + 16-bit copy + partial statistics
+    x, xb = x0.clone(), torch.zeros(M, D, device="cuda", dtype=torch.bfloat16)
+    part = torch.full((D // 64, M, 2), float("nan"), device="cuda")
+    ops.gemm_bf16(a, wo, bias=bo, residual=x, out_f32=x, out_bf16=xb, rowstats_out=part)
+    x_plain = x0.clone()
+    ops.gemm_bf16(a, wo, bias=bo, residual=x_plain, out_f32=x_plain, tile_config=3)
+    assert torch.equal(x, x_plain)                                       # the fp32 stream is bit-identical to the plain residual form
+    assert torch.equal(xb, x.bfloat16())
+    stats = torch.empty(M, 2, device="cuda")
+    ops.rowstats_combine(part, stats, rows=M, D=D)
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    assert (stats[:, 0].double() - mean).abs().max() < 1e-5
+    assert ((stats[:, 1].double() - (var + 1e-5).rsqrt()) / (var + 1e-5).rsqrt()).abs().max() < 1e-5
+    # consumer: LayerNorm(x) W^T + b with the fold, against LayerNorm + plain GEMM
+    gamma = 1.0 + 0.3 * torch.randn(D, device="cuda", generator=g)
+    beta = 0.2 * torch.randn(D, device="cuda", generator=g)
+    w = (torch.randn(N, D, device="cuda", generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    ws = (w.float() * gamma[None, :]).bfloat16().contiguous()
+    c1 = ws.float().sum(1).contiguous()
+    c2 = (w.float() @ beta + b).contiguous()
+    for act in (0, 1):
+        y = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_bf16(xb, ws, bias=c2, act=act, out_bf16=y, ln_stats=stats, ln_c1=c1)
+        ref = _ref_act(torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5) @ w.float().t() + b, act, None)
+        _report(f"fold act{act}", y, ref, 1.2e-2)
+        # and against the unfused pair on the device (LayerNorm kernel -> 16-bit -> GEMM): same size of 16-bit rounding error
+        xn = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        ops.layernorm_fwd(x, gamma, beta, rows=M, out_bf16=xn)
+        y2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_bf16(xn, w, bias=b, act=act, out_bf16=y2, tile_config=8)
+        e_fold = (y.float() - ref).abs().max().item()
+        e_pair = (y2.float() - ref).abs().max().item()
+        assert e_fold < 2.5 * e_pair + 1e-3, (e_fold, e_pair)
+    with pytest.raises(RuntimeError):          # whole 256-row tiles only
+        ops.gemm_bf16(xb[:300], ws, bias=c2, out_bf16=torch.zeros(300, N, device="cuda", dtype=torch.bfloat16), ln_stats=stats, ln_c1=c1)
