@@ -109,7 +109,7 @@ class BlockStack:
 
     def fold_enabled(self) -> bool:
         import os
-        return os.environ.get("CCLIP_LN_FOLD", "1") != "0" and self.geo.linear_layout and not self.fp8
+        return os.environ.get("CCLIP_LN_FOLD", "0") == "1" and self.geo.linear_layout and not self.fp8
 
     def _fold_weights(self, version):
         """Per block: W' = gamma (.) W as 16-bit operands, c1 = row sums of W' (fp32, of the ROUNDED values: the folded epilogue's
@@ -198,10 +198,13 @@ class BlockStack:
         # projection (fc, qkv of the next block) multiplies the RAW rows by W' = gamma (.) W and applies mean / rstd in its epilogue:
         # LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (W beta + b).  24 of a ViT-B/32 tower's 25 standalone LayerNorm passes
         # (a read of the fp32 stream + a 16-bit write each) disappear; block 0's ln_1 and the pooled final LayerNorm stay.
-        # Needs whole 256-row / 256-column tiles (tile configuration 8); CCLIP_LN_FOLD=0 switches it off.
+        # Needs whole 256-row / 256-column tiles (tile configuration 8).  OFF by default (CCLIP_LN_FOLD=1 enables it): measured on
+        # ViT-B/32 bs 1024 (profiles/r03_ln_fold_ab.txt) it is a wash with two lanes and 2 % SLOWER on one stream - the standalone
+        # LayerNorm kernels run at the HBM roofline and overlap the other lane's GEMMs, while the bytes they save come back as extra
+        # store instructions in the residual GEMMs' epilogue, which is store-issue bound and serial on its CU.
         import os
         fold = (not train and weights_version is not None and kc and cu is None and kv_out is None and not self.fp8
-                and os.environ.get("CCLIP_LN_FOLD", "1") != "0" and geo.head_dim == 64 and geo.act in (ops.ACT_NONE, ops.ACT_QUICKGELU)
+                and os.environ.get("CCLIP_LN_FOLD", "0") == "1" and geo.head_dim == 64 and geo.act in (ops.ACT_NONE, ops.ACT_QUICKGELU)
                 and M % 256 == 0 and D % 256 == 0 and Hd % 256 == 0 and D >= 128)
         if fold:
             fw = self._fold_weights(weights_version)

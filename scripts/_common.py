@@ -19,25 +19,28 @@ for _p in (ROOT, os.path.join(ROOT, "construction-clip_amd")):
 SOT, EOT = 49406, 49407
 
 
-def byte_tokenize(texts, context_length: int = 77) -> torch.Tensor:
+def byte_tokenize(texts, context_length: int = 77, vocab_size: int = 49408) -> torch.Tensor:
     """Stand-in for clip.tokenize when the BPE vocabulary (bpe_simple_vocab_16e6.txt.gz) is not on disk: [SOT] + one id per
-    UTF-8 byte (1 + byte value) + [EOT], zero padded, over-long texts cut (the real tokenizer raises instead).  Token ids stay
-    inside the model's vocabulary and EOT stays the largest id of a row, which is all encode_text relies on."""
+    UTF-8 byte + [EOT], zero padded, over-long texts cut (the real tokenizer raises instead).  SOT / EOT are the model's two
+    largest ids (49406 / 49407 for the real vocabulary), so EOT stays the largest id of a row - all encode_text relies on."""
     if isinstance(texts, str):
         texts = [texts]
+    sot, eot = vocab_size - 2, vocab_size - 1
     out = torch.zeros(len(texts), context_length, dtype=torch.int32)
     for i, t in enumerate(texts):
-        ids = [SOT] + [1 + b for b in t.encode("utf-8")][: context_length - 2] + [EOT]
+        ids = [sot] + [1 + b % (vocab_size - 3) for b in t.encode("utf-8")][: context_length - 2] + [eot]
         out[i, : len(ids)] = torch.tensor(ids, dtype=torch.int32)
     return out
 
 
-def get_tokenize():
-    """clip.tokenize when a vocabulary file is configured (CCLIP_BPE_PATH), the byte stand-in otherwise."""
+def get_tokenize(model=None):
+    """clip.tokenize when a vocabulary file is configured (CCLIP_BPE_PATH), the byte stand-in otherwise; sized for `model`."""
+    import functools
+    ctx = getattr(model, "context_length", 77)
     if os.environ.get("CCLIP_BPE_PATH"):
         import clip
-        return clip.tokenize
-    return byte_tokenize
+        return functools.partial(clip.tokenize, context_length=ctx)
+    return functools.partial(byte_tokenize, context_length=ctx, vocab_size=getattr(model, "vocab_size", 49408))
 
 
 class ByteCaptionTokenizer:

@@ -38,7 +38,7 @@ def main(argv=None):
         model.load_state_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=True))   # predict.py:14-16
     model.eval()
     image = torch.stack([preprocess(Image.open(p)) for p in args.images]).to(device)     # predict.py:28-34
-    text = C.get_tokenize()(args.prompts, context_length=model.context_length).to(device)                                      # predict.py:39-40
+    text = C.get_tokenize(model)(args.prompts).to(device)                                      # predict.py:39-40
     with torch.no_grad():
         logits_per_image, _ = model(image, text)                                          # predict.py:46
         similarity = logits_per_image.softmax(dim=-1)                                     # predict.py:47

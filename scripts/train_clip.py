@@ -72,8 +72,7 @@ def main(argv=None):
     model, preprocess = clip.load(args.model, device=device, jit=False)
     if args.checkpoint:
         model.load_state_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=True))
-    import functools
-    tokenize = functools.partial(C.get_tokenize(), context_length=model.context_length)
+    tokenize = C.get_tokenize(model)
     mk = lambda split: ClipPairDataset(preprocess, args.json, args.image_path, args.train_ratio, args.key, split,   # noqa: E731
                                        args.combination_num, tokenize=tokenize)
     train_ds, test_ds = mk("train"), mk("test")

@@ -16,9 +16,21 @@ NLOC, WORLD, MODEL, SEED = 6, 2, "test-small", 31
 
 
 def _batch():
+    """One global batch whose two rank slices hold captions of very different total length: rank 0's end at position 3, rank 1's
+    at position >= 18 (of 24) - the packed text tower then runs on 24 rows on rank 0 and >= 114 on rank 1, so the ranks' GEMM
+    shapes, tile lookups and launch geometry differ (what `bench.py --gpus N` does by default with its per-rank seeds)."""
     from clip.weights import MODELS, synthetic_images, synthetic_text
     geo = MODELS[MODEL]
-    return synthetic_images(NLOC * WORLD, geo, SEED + 1), synthetic_text(NLOC * WORLD, geo, SEED + 2)
+    txt = synthetic_text(NLOC * WORLD, geo, SEED + 2)
+    eot = int(txt.max())
+    g = torch.Generator().manual_seed(SEED + 3)
+    for b in range(NLOC * WORLD):
+        body = torch.randint(1, eot - 2, (geo.context_length,), generator=g, dtype=txt.dtype)
+        end = 3 if b < NLOC else 18 + (b % 4)
+        txt[b, 1:end] = body[1:end]
+        txt[b, end] = eot
+        txt[b, end + 1:] = 0
+    return synthetic_images(NLOC * WORLD, geo, SEED + 1), txt
 
 
 def _worker(rank, port, out_dir):
@@ -57,6 +69,8 @@ def test_two_rank_step_equals_single_process(tmp_path):
     dp = torch.load(os.path.join(tmp_path, "dp.pt"), weights_only=True)
     model = clip.build_model(init_state_dict(MODELS[MODEL], SEED)).cuda().train()
     img, txt = _batch()
+    live = (txt.argmax(-1) + 1)
+    assert int(live[:NLOC].sum()) * 4 < int(live[NLOC:].sum())      # the ranks' packed row counts differ by more than 4x
     loss, stats = clip.contrastive_loss(model.encode_image(img.cuda()), model.encode_text(txt.cuda()), model.logit_scale)
     loss.backward()
     assert abs(loss.item() - dp["loss"].item()) < 1e-5

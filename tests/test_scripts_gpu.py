@@ -41,9 +41,7 @@ def test_train_clip_script_three_steps_and_first_loss_matches_oracle(tmp_path, c
     d = tmp_path / "syn"
     js = C.make_synthetic_annotations(str(d))
     model, preprocess = clip.load("test-small", device="cuda:0")
-    import functools
-    ds = ClipPairDataset(preprocess, js, str(d), 0.8, "violation_type", "train", 9,
-                         tokenize=functools.partial(C.byte_tokenize, context_length=model.context_length))
+    ds = ClipPairDataset(preprocess, js, str(d), 0.8, "violation_type", "train", 9, tokenize=C.get_tokenize(model))
     image, text = ds[0]
     with torch.no_grad():
         li, lt = model(image.cuda(), text.cuda())
