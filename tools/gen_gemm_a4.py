@@ -85,6 +85,12 @@ def dma_pairs():
 ADVANCE = ["s_add_u32 s60, s60, 128", "s_addc_u32 s61, s61, 0", "s_add_u32 s62, s62, 128", "s_addc_u32 s63, s63, 0",
            "s_xor_b32 s65, s65, 0x10000"]
 TOGGLE = [f"v_xor_b32 v{r}, 0x10000, v{r}" for r in (144, 145, 146, 147)]
+# L2 prefetch stream (variant {"pf": 2}; measured in round 3 and NOT instantiated: -3 % on the K = 3072 projection, +2 % on the K = 768 ones -
+# the activation rows a projection reads were written by the kernel before it and sit in the Infinity Cache): one dword per 128-byte line of the A tile's K-slab `pf` K-tiles ahead of the DMA stream - lane l of
+# wave w touches row 64 w + l (offset v149, destination v148 never read).  s[72:73] = its source, advanced while s74 > 0.
+PF_STEP = ["s_cmp_lg_u32 s74, 0", "s_cselect_b32 s75, 128, 0", "s_cselect_b32 s76, 1, 0", "s_add_u32 s72, s72, s75", "s_addc_u32 s73, s73, 0",
+           "s_sub_u32 s74, s74, s76"]
+PF_LOAD = "global_load_dword v148, v149, s[72:73]"
 
 
 def phase(mf, fillers):
@@ -110,6 +116,10 @@ def phase_R(dma, variant):
                 fill.setdefault(4 * (r // 2) + 2 + (r % 2), []).append(ins)
             fill.setdefault(62, []).extend(ADVANCE[:2])
             fill.setdefault(63, []).extend(ADVANCE[2:])
+            if variant.get("pf"):           # L2 prefetch of the A rows of K-tile kt + 1 + pf: youngest operation of the iteration
+                fill.setdefault(61, []).append(PF_LOAD)        # (after the last DMA of the group, which sits in this gap too)
+                fill.setdefault(62, []).extend(PF_STEP[:3])
+                fill.setdefault(63, []).extend(PF_STEP[3:])
         else:                               # dma_spread == 2: DMA group in the first half, reads in the second
             for j, (m0, ld) in enumerate(pairs):
                 fill.setdefault(2 * j, []).append(m0)
@@ -135,7 +145,12 @@ def phase_Q(variant):
 
 def kloop(variant):
     L = []
+    pf = variant.get("pf", 0)
+    wait = f"s_waitcnt vmcnt({1 if pf else 0})"
     L += ["s_mov_b64 s[60:61], %[abase]", "s_mov_b64 s[62:63], %[bbase]", "s_mov_b32 s64, %[niter]", "s_mov_b32 s65, %[m0base]"]
+    if pf:
+        # the prefetch stream starts at K-tile 2 (tiles 0 and 1 are staged right away) and runs up to the last K-tile: nkt - 3 advances
+        L += ["s_mov_b64 s[72:73], %[abase]", "s_add_u32 s72, s72, 256", "s_addc_u32 s73, s73, 0", "s_sub_u32 s74, s64, 1", "s_max_i32 s74, s74, 0"]
     L.append("s_nop 4")
     # prologue: tile 0 -> stage 0
     for m0, ld in dma_pairs():
@@ -148,13 +163,16 @@ def kloop(variant):
     for m0, ld in dma_pairs():              # tile 1 -> stage 1 (nkt >= 2 is a launch condition)
         L += [m0, "s_nop 0", ld]
     L += ADVANCE
+    if pf:
+        for _ in range(pf):                 # K-tiles 2 .. 1 + pf: nothing else will touch their lines before their DMA
+            L += [PF_LOAD] + PF_STEP
     L += reads(0, 0)
     L += ["s_waitcnt lgkmcnt(0)"]
     L += phase_Q(variant)
     L += ["s_waitcnt lgkmcnt(0)"]
     L += ["s_cmp_eq_u32 s64, 0", "s_cbranch_scc1 LAST_%="]
     L += ["LOOP_%=:"]
-    L += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    L += [wait, "s_barrier"]
     L += phase_R(True, variant)
     L += ["s_waitcnt lgkmcnt(0)"]
     L += phase_Q(variant)
@@ -179,20 +197,25 @@ def clobbers():
 
 
 def emit(variant, name):
+    pf = variant.get("pf", 0)
     """The asm statement as a macro.  Operands pinned to physical registers: the 64 accumulators ACC[8 mt + nt] (f32x4 each; wider pinned tuples crash this compiler's copy lowering)
     (outputs: the compiler owns them afterwards and reads them in the epilogue), the DMA offsets v[128:143] (inputs) and the
     LDS read addresses v[144:147] (in/out: the loop toggles their stage bit)."""
     lines = kloop(variant)
     s = [f"// GENERATED by tools/gen_gemm_a4.py (variant {variant}) - do not edit; the K loop of gemm_a4_kernel as one asm statement.",
-         f"#define {name}(ACC, ABASE, BBASE, NITER, M0BASE, OA03, OA47, OB03, OB47, LADDR) \\", "  asm volatile( \\"]
+         f"#define {name}(ACC, ABASE, BBASE, NITER, M0BASE, OA03, OA47, OB03, OB47, LADDR{', PFOFF' if pf else ''}) \\", "  asm volatile( \\"]
     for ln in lines:
         s.append(f'    "{ln}\\n\\t" \\')
     outs = [f'"={{a[{4 * i}:{4 * i + 3}]}}"(ACC[{i}])' for i in range(64)] + ['"+{v[144:147]}"(LADDR)']
     s.append("    : " + ", ".join(outs) + " \\")
     ops = ['[abase] "s"(ABASE)', '[bbase] "s"(BBASE)', '[niter] "s"(NITER)', '[m0base] "s"(M0BASE)',
            '"{v[128:131]}"(OA03)', '"{v[132:135]}"(OA47)', '"{v[136:139]}"(OB03)', '"{v[140:143]}"(OB47)']
+    cl = clobbers()
+    if pf:
+        ops.append('"{v149}"(PFOFF)')
+        cl += ['"v148"'] + [f'"s{i}"' for i in range(72, 77)]
     s.append("    : " + ", ".join(ops) + " \\")
-    s.append("    : " + ", ".join(clobbers()) + ")")
+    s.append("    : " + ", ".join(cl) + ")")
     return "\n".join(s) + "\n"
 
 
