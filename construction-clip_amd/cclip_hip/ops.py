@@ -227,6 +227,8 @@ def _nearest_tuned(key: str, unbounded: bool = False):
             cfg = 3           # the hand-scheduled configurations need whole 64-deep K-tiles
     if tok == 3 and sp > 1:
         sp = max(1, min(sp, round(sp * want / toks[best])))
+    if tok == 3 and cfg == 11 and (want % 64 or want // 64 < 2 * sp):
+        cfg = 2               # the hand-scheduled weight-gradient kernel needs whole 64-token K-tiles, >= 2 per split
     return (cfg, sp)
 
 

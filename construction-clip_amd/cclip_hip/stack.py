@@ -68,7 +68,7 @@ def wgrad_candidates(n_out: int, k_in: int, tokens: int):
     concurrent workgroups (512 for the 128x128 tile, 256 for the 256x128, 256x256 and 192x256 tiles), >= 4 K-tiles per split."""
     nkt = (tokens + 63) // 64
     cands = []
-    for cfg, em, en, slots in ((1, 128, 128, 512), (2, 256, 128, 256), (3, 256, 256, 256), (5, 192, 256, 256)):
+    for cfg, em, en, slots in ((1, 128, 128, 512), (2, 256, 128, 256), (3, 256, 256, 256), (5, 192, 256, 256), (11, 256, 256, 256)):
         tiles = ((n_out + em - 1) // em) * ((k_in + en - 1) // en)
         for mult in (1, 2, 3):
             s = max(1, min(64, (slots * mult) // max(tiles, 1)))

@@ -39,6 +39,7 @@ bool cclip_gemm_launch_cfg5(int lay, int act, dim3 grid, hipStream_t stream, con
 bool cclip_gemm_launch_cfg7(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_cfg8(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a, int variant);
 bool cclip_gemm_launch_cfg10(int lay, int act, hipStream_t stream, const GemmArgs& a);
+bool cclip_gemm_launch_cfg11(int lay, int act, dim3 grid, hipStream_t stream, const GemmArgs& a);
 bool cclip_gemm_launch_skinny(int lay, int act, hipStream_t stream, const GemmArgs& a);
 
 // ---- split-K combine: out = epilogue(sum_z ws[z]) ; 8 columns per thread ----
@@ -183,6 +184,17 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
   }
   if (cfg == 10) {              // the same tile and K loop as a persistent kernel (cross-tile operand prefetch): K % 64 == 0, K >= 192
     if (splits > 1 || !cclip_gemm_launch_cfg10(d->a_kcontig * 2 + d->b_kcontig, d->act, stream, a)) return CCLIP_ERR_ARG;
+    return cclip_launch_status();
+  }
+  if (cfg == 11) {              // hand-scheduled 4-wave weight-gradient kernel (gemm_bf16_cfg11.hip): layout (0,0), K % 64 == 0
+    const int tiles11 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+    if (!cclip_gemm_launch_cfg11(d->a_kcontig * 2 + d->b_kcontig, d->act, dim3(tiles11, splits), stream, a)) return CCLIP_ERR_ARG;
+    int st11 = cclip_launch_status();
+    if (st11 != CCLIP_OK || splits == 1) return st11;
+    long total = (long)d->M * d->N / 4;
+    int blocks = (int)((total + 255) / 256); if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d->split_ws, splits, d->M, d->N,
+                       d->alpha, d->residual, d->ldr, d->out_f32, (bf16*)d->out_bf16, d->ldc, a.colsum_ws, a.colsum_dst, a.colsum_acc, d->M);
     return cclip_launch_status();
   }
   if (cfg <= 0 || cfg > 7 || cfg == 6) cfg = (d->M >= 2048 && getenv("CCLIP_GEMM_CFG") ? atoi(getenv("CCLIP_GEMM_CFG")) : 1);

@@ -218,6 +218,44 @@ def test_gemm_cfg8_refuses_what_it_does_not_implement():
         ops.gemm_bf16(A2, Bt, a_kcontig=True, b_kcontig=False, out_f32=out, tile_config=8)
 
 
+@pytest.mark.parametrize("M,N,K,split", [(256, 256, 256, 1), (768, 768, 1024, 2), (2304, 768, 6400, 5), (304, 264, 1280, 3), (3072, 768, 4096, 4)])
+def test_gemm_cfg11_weight_gradient_layout(M, N, K, split):
+    """Configuration 11 (four 128x128 waves, hand-scheduled asm K loop with transposing LDS reads): the weight-gradient layout -
+    both operands K-strided, split-K slabs, the fused bias gradient (row sums of A).  Same summation order as the 8-wave 256x128
+    configuration 2 at the same split -> bit-identical, bias gradient included."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn((K, M), device="cuda", generator=g).bfloat16()       # dY  [tokens, out]
+    B = torch.randn((K, N), device="cuda", generator=g).bfloat16()       # X   [tokens, in]
+    ref = A.float().t() @ B.float()
+    res = {}
+    for cfg in (11, 2):           # (2 = the 256x128 8-wave kernel the training step used for its weight gradients)
+        out = torch.full((M, N), float("nan"), device="cuda")
+        cs = torch.full((M,), float("nan"), device="cuda")
+        ws = torch.empty(split * (M * N + max(M, N)), device="cuda") if split > 1 else None
+        ops.gemm_bf16(A, B, a_kcontig=False, b_kcontig=False, out_f32=out, tile_config=cfg, split_k=split, split_ws=ws, colsum_out=cs)
+        res[cfg] = (out, cs)
+    torch.cuda.synchronize()
+    _report(f"wgrad {M}x{N}x{K} cfg11", res[11][0], ref, 2e-3)
+    assert (res[11][1] - A.float().sum(0)).abs().max() < 2e-3 * A.float().abs().sum(0).max()
+    assert torch.equal(res[11][0], res[2][0])
+    assert torch.equal(res[11][1], res[2][1])
+    # accumulate into an existing gradient (residual = out) and into an existing bias gradient
+    out = ref.clone(); cs = torch.ones(M, device="cuda")
+    ws = torch.empty(split * (M * N + max(M, N)), device="cuda") if split > 1 else None
+    ops.gemm_bf16(A, B, a_kcontig=False, b_kcontig=False, residual=out, out_f32=out, tile_config=11, split_k=split, split_ws=ws,
+                  colsum_out=cs, colsum_accumulate=True)
+    _report("wgrad accumulate", out, 2 * ref, 2e-3)
+    assert (cs - 1 - A.float().sum(0)).abs().max() < 2e-3 * A.float().abs().sum(0).max()
+
+
+def test_gemm_cfg11_refuses_ragged_contraction():
+    ops = _ops()
+    A = torch.randn(200, 256, device="cuda").bfloat16(); B = torch.randn(200, 256, device="cuda").bfloat16()
+    with pytest.raises(RuntimeError):        # K % 64 != 0
+        ops.gemm_bf16(A, B, a_kcontig=False, b_kcontig=False, out_f32=torch.empty(256, 256, device="cuda"), tile_config=11)
+
+
 def test_gemm_residual_inplace_and_ld():
     """out_f32 aliases residual (x += ...), outputs with a row stride larger than N."""
     ops = _ops()

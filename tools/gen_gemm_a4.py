@@ -349,6 +349,128 @@ def emit_pers(variant, name):
 
 PERS_VARIANTS = {"GEMM_A4P": {"order": "mt_outer"}}
 
+# ======================================================================================================================
+# Weight-gradient form (tile configuration 11): both operands K-STRIDED (dW = dY^T X, the contraction runs over tokens): the same
+# four 128x128 waves and rotated BK = 64 loop, fragments by ds_read_b64_tr_b16 (hardware transpose) from the [64 k][128 col]
+# sub-tile image of the other configurations.
+#   LDS: region(X, stage) at X * 32768 + stage * 16384, X = A sub-tile 0 / 1, B sub-tile 0 / 1 - the stage is an IMMEDIATE
+#   offset, the loop is unrolled by two (one body per stage), no address toggling.
+#   registers: v[144:207] LDS read addresses: v[144 + 32 op + 4 t + 2 ks + h] = transposing read (half h) of tile t, k-step ks;
+#   v[208:239] the bias gradient's accumulators (row sums of dY^T by 8 extra MFMAs per k-step against an all-ones fragment,
+#   v[240:243]; only in tiles of the first column block: s68); s66 / s67 A / B source stride per K-tile (64 rows).
+def wg_reads(stage, set_, ks):
+    """32 transposing reads of k-step ks of the tile in `stage` into fragment set set_ (weight fragments first)."""
+    out = []
+    for op in (1, 0):
+        for t in range(8):
+            for h in range(2):
+                va = 144 + 32 * op + 4 * t + 2 * ks + h
+                b = 64 * set_ + (32 if op else 0) + 4 * t + 2 * h
+                # (the operand's region and the wave's sub-tile are folded into the address register: the offset field is 16 bits)
+                out.append(f"ds_read_b64_tr_b16 v[{b}:{b + 1}], v{va} offset:{stage * 16384}")
+    return out
+
+
+def wg_dma(stage):
+    out = []
+    for op, (base, sreg) in enumerate(((128, "s[60:61]"), (136, "s[62:63]"))):
+        for i in range(8):
+            dst = (2 * op + (i >> 2)) * 32768 + stage * 16384 + (i & 3) * 4096
+            out.append((f"s_add_u32 m0, s65, {dst}", f"global_load_lds_dwordx4 v{base + i}, {sreg}"))
+    return out
+
+
+WG_ADVANCE = ["s_add_u32 s60, s60, s66", "s_addc_u32 s61, s61, 0", "s_add_u32 s62, s62, s67", "s_addc_u32 s63, s63, 0"]
+
+
+def wg_mfma(set_, cs):
+    out = []
+    for mt in range(8):
+        for nt in range(8):
+            out.append(f"{MFMA} {acc(mt, nt)}, {bfrag(set_, nt)}, {afrag(set_, mt)}, {acc(mt, nt)}")
+        if cs:
+            b = 208 + 4 * mt
+            out.append(f"{MFMA} v[{b}:{b + 3}], v[240:243], {afrag(set_, mt)}, v[{b}:{b + 3}]")
+    return out
+
+
+def wg_phase(set_, cs, rd, dma):
+    """MFMAs on fragment set set_ with the 32 reads `rd` and (optionally) the 16 DMA pairs `dma` dealt into the gaps."""
+    mf = wg_mfma(set_, cs)
+    n = len(mf)
+    fill = {}
+    if dma:
+        for j, (m0, ld) in enumerate(dma):
+            fill.setdefault(4 * j, []).append(m0)
+            fill.setdefault(4 * j + 1, []).append(ld)
+        fill.setdefault(n - 2, []).extend(WG_ADVANCE[:2])
+        fill.setdefault(n - 1, []).extend(WG_ADVANCE[2:])
+    for r, ins in enumerate(rd or []):
+        fill.setdefault(min(2 + (r * (n - 8)) // 32, n - 3), []).append(ins)
+    return phase(mf, fill)
+
+
+def wg_iter(stage, cs, dma):
+    """One K iteration on the tile in `stage`: k-step 1 of the previous tile (+ DMA of the next tile into the other stage + reads of
+    k-step 0), then k-step 0 (+ reads of k-step 1)."""
+    L = ["s_waitcnt vmcnt(0)", "s_barrier"]
+    L += wg_phase(1, cs, wg_reads(stage, 0, 0), wg_dma(stage ^ 1) if dma else None) + ["s_waitcnt lgkmcnt(0)"]
+    L += wg_phase(0, cs, wg_reads(stage, 1, 1), None) + ["s_waitcnt lgkmcnt(0)"]
+    return L
+
+
+def wg_body(cs, tag):
+    L = []
+    # kt = 0 (stage 0): no previous tile
+    L += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    for m0, ld in wg_dma(1):
+        L += [m0, "s_nop 0", ld]
+    L += WG_ADVANCE
+    L += wg_reads(0, 0, 0) + ["s_waitcnt lgkmcnt(0)"]
+    L += wg_phase(0, cs, wg_reads(0, 1, 1), None) + ["s_waitcnt lgkmcnt(0)"]
+    L += [f"WLOOP{tag}_%=:", "s_cmp_eq_u32 s64, 0", f"s_cbranch_scc1 WLAST1{tag}_%="]
+    L += wg_iter(1, cs, True) + ["s_sub_u32 s64, s64, 1", "s_cmp_eq_u32 s64, 0", f"s_cbranch_scc1 WLAST0{tag}_%="]
+    L += wg_iter(0, cs, True) + ["s_sub_u32 s64, s64, 1", f"s_branch WLOOP{tag}_%="]
+    L += [f"WLAST1{tag}_%=:"] + wg_iter(1, cs, False) + [f"s_branch WTAIL{tag}_%="]
+    L += [f"WLAST0{tag}_%=:"] + wg_iter(0, cs, False)
+    L += [f"WTAIL{tag}_%=:"] + wg_mfma(1, cs)
+    return L
+
+
+def wg_kloop():
+    L = ["s_mov_b64 s[60:61], %[abase]", "s_mov_b64 s[62:63], %[bbase]", "s_mov_b32 s64, %[niter]", "s_mov_b32 s65, %[m0base]",
+         "s_mov_b32 s66, %[astride]", "s_mov_b32 s67, %[bstride]", "s_mov_b32 s68, %[cs]", "s_nop 4"]
+    for m0, ld in wg_dma(0):
+        L += [m0, "s_nop 0", ld]
+    L += WG_ADVANCE
+    for i in range(256):
+        L.append(f"v_accvgpr_write_b32 a{i}, 0")
+    for i in range(208, 240):
+        L.append(f"v_mov_b32 v{i}, 0")
+    L += ["s_cmp_eq_u32 s68, 0", "s_cbranch_scc1 WPLAIN_%="]
+    L += wg_body(True, "C") + ["s_branch WEND_%="]
+    L += ["WPLAIN_%=:"] + wg_body(False, "P")
+    L += ["WEND_%=:", "s_nop 15", "s_nop 15"]
+    return L
+
+
+def emit_wg(name):
+    s = ["// GENERATED by tools/gen_gemm_a4.py (weight-gradient form) - do not edit.",
+         f"#define {name}(ACC, ACCB, ABASE, BBASE, NITER, M0BASE, ASTRIDE, BSTRIDE, CS, OA03, OA47, OB03, OB47, LA, ONES) \\", "  asm volatile( \\"]
+    for ln in wg_kloop():
+        s.append(f'    "{ln}\\n\\t" \\')
+    outs = [f'"={{a[{4 * i}:{4 * i + 3}]}}"(ACC[{i}])' for i in range(64)] + [f'"={{v[{208 + 4 * i}:{211 + 4 * i}]}}"(ACCB[{i}])' for i in range(8)]
+    s.append("    : " + ", ".join(outs) + " \\")
+    ops = ['[abase] "s"(ABASE)', '[bbase] "s"(BBASE)', '[niter] "s"(NITER)', '[m0base] "s"(M0BASE)', '[astride] "s"(ASTRIDE)',
+           '[bstride] "s"(BSTRIDE)', '[cs] "s"(CS)',
+           '"{v[128:131]}"(OA03)', '"{v[132:135]}"(OA47)', '"{v[136:139]}"(OB03)', '"{v[140:143]}"(OB47)']
+    ops += [f'"{{v[{144 + 4 * i}:{147 + 4 * i}]}}"(LA[{i}])' for i in range(16)] + ['"{v[240:243]}"(ONES)']
+    s.append("    : " + ", ".join(ops) + " \\")
+    cl = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(60, 69)] + [f'"v{i}"' for i in range(0, 128)]
+    s.append("    : " + ", ".join(cl) + ")")
+    return "\n".join(s) + "\n"
+
+
 VARIANTS = {
     "GEMM_A4R": {"order": "mt_outer", "read_gap0": 2, "read_stride": 2, "dma_gap0": 4, "dma_stride": 7},
 }
@@ -361,3 +483,7 @@ if __name__ == "__main__":
     txt = "".join(emit(v, n) + "\n" for n, v in VARIANTS.items()) + "".join(emit_pers(v, n) + "\n" for n, v in PERS_VARIANTS.items())
     open(OUT, "w").write(txt)
     print(f"wrote {OUT}: {len(txt.splitlines())} lines")
+    wout = OUT.replace("gemm_a4_kloop.inc", "gemm_a4w_kloop.inc")
+    wtxt = emit_wg("GEMM_A4W_KLOOP")
+    open(wout, "w").write(wtxt)
+    print(f"wrote {wout}: {len(wtxt.splitlines())} lines")
