@@ -154,8 +154,14 @@ class BlockStack:
         Hd = self.geo.hidden or 4 * D
         T = T or self.geo.tokens
         M, L = (M or B * T), len(self.blocks)
-        return dict(T=T, M=M, cu=None,
-            bf=torch.empty(L, M, 6 * D + 2 * Hd, device=device, dtype=self.dtype),   # xn1 | qkv | a | xn2 | h | g
+        # The 16-bit activation slab is allocated on whole 64-row K-tiles with its tail rows ZERO: the weight-gradient GEMMs contract
+        # over tokens, and the hand-scheduled kernel (tile configuration 11) only takes whole K-tiles - a packed text batch has an
+        # arbitrary row count.  Rows [M, Mp) are never written (every launch is told M), so they stay zero and add exact zeros.
+        Mp = (M + 63) // 64 * 64
+        bf = torch.empty(L, Mp, 6 * D + 2 * Hd, device=device, dtype=self.dtype)   # xn1 | qkv | a | xn2 | h | g
+        if Mp != M:
+            bf[:, M:].zero_()
+        return dict(T=T, M=M, Mp=Mp, cu=None, bf=bf,
             xs=torch.empty(L, 2, M, D, device=device, dtype=torch.float32),      # x_in, x_mid
             st=torch.empty(L, 4, M, device=device, dtype=torch.float32),         # mean1 rstd1 mean2 rstd2
             lse=torch.empty(L, B, H, T, device=device, dtype=torch.float32),
@@ -339,7 +345,7 @@ class BlockStack:
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dy: torch.Tensor, xin: torch.Tensor, gw: torch.Tensor, M: int, acc: bool, scratch=None,
-               gb: Optional[torch.Tensor] = None, acc_b: bool = False, fixed: bool = False):
+               gb: Optional[torch.Tensor] = None, acc_b: bool = False, fixed: bool = False, pad: bool = False):
         """gw (+)= dy^T xin for nn.Linear layout [out,in]; xin^T dy for Conv1D layout [in,out].
         gb: the layer's bias gradient (+)= column sums of dy: dy is an operand of this GEMM (A for nn.Linear weights, B for
         Conv1D ones), so the sums ride on the same launch - one extra MFMA per tile row / column against an all-ones fragment
@@ -355,8 +361,12 @@ class BlockStack:
             ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw, tile_config=1,
                           split_k=sp, split_ws=ws, colsum_out=gb, colsum_accumulate=acc_b, colsum_of_b=not lin)
             return
-        ops.gemm_bf16(a[:M], b[:M], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
-                      split_candidates=wgrad_candidates(n_out, k_in, M), scratch=(scratch or self.scratch).floats,
+        # both operands from this stack's zero-tailed slabs (alloc_saved / backward): contract over whole 64-row K-tiles
+        Mk = (M + 63) // 64 * 64
+        if not (pad and a.shape[0] >= Mk and b.shape[0] >= Mk):
+            Mk = M
+        ops.gemm_bf16(a[:Mk], b[:Mk], a_kcontig=False, b_kcontig=False, residual=gw if acc else None, out_f32=gw,
+                      split_candidates=wgrad_candidates(n_out, k_in, Mk), scratch=(scratch or self.scratch).floats,
                       colsum_out=gb, colsum_accumulate=acc_b, colsum_of_b=not lin)
 
     def _bgrad(self, dy: torch.Tensor, gb: torch.Tensor, M: int, acc: bool, scratch=None):
@@ -381,6 +391,7 @@ class BlockStack:
         Hd = geo.hidden or 4 * D
         B, T = saved["B"], saved["T"]
         M = saved.get("M") or B * T
+        Mp = saved.get("Mp") or M          # rows of the zero-tailed 16-bit slabs (whole 64-row K-tiles for the weight gradients)
         L = len(self.blocks)
         dev = dx.device
         kc = geo.linear_layout
@@ -398,12 +409,16 @@ class BlockStack:
         cur = torch.cuda.current_stream() if dev.type == "cuda" else None
         if side is not None:
             side.wait_stream(cur)
-            dh_all = torch.empty(L, M, Hd, device=dev, dtype=self.dtype)
-            dqkv_all = torch.empty(L, M, 3 * D, device=dev, dtype=self.dtype)
-            dxb_all = torch.empty(2 * L, M, D, device=dev, dtype=self.dtype)
+            dh_all = torch.empty(L, Mp, Hd, device=dev, dtype=self.dtype)
+            dqkv_all = torch.empty(L, Mp, 3 * D, device=dev, dtype=self.dtype)
+            dxb_all = torch.empty(2 * L, Mp, D, device=dev, dtype=self.dtype)
             tmp = torch.empty(M, D, device=dev, dtype=self.dtype)
+            if Mp != M:                          # zero tail rows: see alloc_saved (operands of the weight-gradient GEMMs)
+                dh_all[:, M:].zero_(); dqkv_all[:, M:].zero_(); dxb_all[:, M:].zero_()
         else:
-            tmp8 = torch.empty(M, 4 * D + Hd, device=dev, dtype=self.dtype)      # dh | dqkv | dxn / da
+            tmp8 = torch.empty(Mp, 4 * D + Hd, device=dev, dtype=self.dtype)      # dh | dqkv | dxn / da
+            if Mp != M:
+                tmp8[M:].zero_()
         ln_ws = self.scratch  # partial sums live in scratch; sized per call
 
         def leaf(fn):
@@ -477,17 +492,21 @@ class BlockStack:
                 dx = torch.zeros(M, D, device=dev, dtype=torch.float32)
                 dx.index_copy_(0, tail["rows"], dx_c)
                 if side is None:
-                    dxb_in = torch.empty(M, D, device=dev, dtype=self.dtype)   # (one-stream mode reuses the caller's dxb, which is compact here)
+                    dxb_in = torch.empty(Mp, D, device=dev, dtype=self.dtype)   # (one-stream mode reuses the caller's dxb, which is compact here)
+                    if Mp != M:
+                        dxb_in[M:].zero_()
             else:
                 # ---- MLP branch ----
                 if gr is not None:
-                    def f1(sc, dxb=dxb, g=g, gr=gr):
-                        self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr))
+                    dxb_is_slab = l != L - 1        # (the stack output's gradient copy belongs to the caller: no zero tail promised)
+
+                    def f1(sc, dxb=dxb, g=g, gr=gr, dxb_is_slab=dxb_is_slab):
+                        self._wgrad(dxb, g, gr["w_proj"], M, A("w_proj", gr), sc, gr["b_proj"], A("b_proj", gr), pad=dxb_is_slab)
                     leaf(f1)
                 ops.gemm_bf16(dxb, wd("w_proj")[0], b_kcontig=wd("w_proj")[1], act=dact, aux=h, out_bf16=dh, M=M)
                 if gr is not None:
                     def f2(sc, dh=dh, xn2=xn2, gr=gr):
-                        self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr))
+                        self._wgrad(dh, xn2, gr["w_fc"], M, A("w_fc", gr), sc, gr["b_fc"], A("b_fc", gr), pad=True)
                     leaf(f2)
                 ops.gemm_bf16(dh, wd("w_fc")[0], b_kcontig=wd("w_fc")[1], out_bf16=dsm, M=M)
                 ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
@@ -498,7 +517,7 @@ class BlockStack:
                 # ---- attention branch ----
                 if gr is not None:
                     def f3(sc, dxb=dxb, a=a, gr=gr):
-                        self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc, gr["b_o"], A("b_o", gr))
+                        self._wgrad(dxb, a, gr["w_o"], M, A("w_o", gr), sc, gr["b_o"], A("b_o", gr), pad=True)
                     leaf(f3)
                 ops.gemm_bf16(dxb, wd("w_o")[0], b_kcontig=wd("w_o")[1], out_bf16=dsm, M=M)
             if geo.head_dim == 64:
@@ -511,7 +530,7 @@ class BlockStack:
             if gr is not None:
                 def f4(sc, dqkv=dqkv, xn1=xn1, gr=gr):
                     gbq = gr.get("b_qkv")                    # TransformerMapper's q / kv projections have no bias
-                    self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc, gbq, A("b_qkv", gr) if gbq is not None else False)
+                    self._wgrad(dqkv, xn1, gr["w_qkv"], M, A("w_qkv", gr), sc, gbq, A("b_qkv", gr) if gbq is not None else False, pad=True)
                 leaf(f4)
             ops.gemm_bf16(dqkv, wd("w_qkv")[0], b_kcontig=wd("w_qkv")[1], out_bf16=dsm, M=M)
             ws = ln_ws.floats(ops.layernorm_bwd_ws_floats(M, D)) if gr is not None else None
@@ -527,4 +546,4 @@ class BlockStack:
         saved["dx_in"] = dx              # (with a compact tail the full-width fp32 gradient is a new tensor, not the argument)
         if side is not None:
             cur.wait_stream(side)        # every parameter gradient is complete before anyone downstream looks at it
-        return dxb
+        return dxb[:M] if dxb.shape[0] != M and dxb.shape[0] == Mp else dxb   # (a zero-tailed slab row: hand back its M live rows)
