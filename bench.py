@@ -14,7 +14,7 @@ N > 1: one process per GPU (torchrun contract), weak scaling (per-GPU batch fixe
 all-gather + reduce-scatter and SUM all-reduce of the flat gradient arena over RCCL.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     - dominant kernel family cclip_gemm_bf16 = gemm_bf16_kernel<*> / gemm_stream_kernel<*> (97 % of the step's
+  roofline     - dominant kernel family cclip_gemm_bf16 = gemm_bf16_kernel<*> / gemm_a4*_kernel / gemm_stream_kernel<*> (97 % of the step's
                  FLOPs, ~78 % of its time): algorithmic FLOPs of
                  every launch in the timed region (2*M*N*K) / their summed durations (HIP events on the launch
                  stream), against the 2.5 PFLOP/s dense bf16 MFMA peak.
@@ -147,7 +147,7 @@ def gemm_roofline(ev, nprof, traffic=None, traffic_src=None):
         t, fl, n = by.get(k, (0.0, 0.0, 0))
         by[k] = (t + e0.elapsed_time(e1), fl + f, n + 1)
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="gemm_bf16_kernel<*> + gemm_stream_kernel<*> (cclip_gemm_bf16: all layouts and tile configs)", achieved=round(ach, 1),
+    return dict(bound="mfma", kernel="gemm_bf16_kernel<*> + gemm_a4_kernel<*> / gemm_a4w_kernel + gemm_stream_kernel<*> (cclip_gemm_bf16: all layouts and tile configs)", achieved=round(ach, 1),
                 peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(ach * 1e12 / PEAK_BF16, 4), traffic=traffic,
                 traffic_unit="HBM-side bytes per launch (PMC, includes Infinity-Cache hits)", traffic_source=traffic_src,
                 flops_per_launch=round(tot_fl / max(len(ev), 1)),

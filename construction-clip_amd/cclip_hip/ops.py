@@ -132,14 +132,14 @@ def _tune_paths():
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the tile-GEMM kernel sources (csrc/gemm_bf16*.hip except the skinny GEMV path and the fp8 kernels, neither of
+    """sha256 over the tile-GEMM kernel sources (csrc/gemm_bf16*.hip and the generated K loops gemm_a4*.inc, except the skinny GEMV path and the fp8 kernels, neither of
     which has tile configurations to choose from; gemm_bf16_impl.h, cclip_common.h): the key a tuned table is valid for."""
     import hashlib, os
     if _TUNE_STATE["source_hash"] is None:
         csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
         h = hashlib.sha256()
         for f in sorted(os.listdir(csrc)):
-            if (f.startswith("gemm_bf16") and "skinny" not in f and "fp8" not in f) or f == "cclip_common.h":
+            if ((f.startswith("gemm_bf16") or f.startswith("gemm_a4")) and "skinny" not in f and "fp8" not in f) or f == "cclip_common.h":
                 h.update(f.encode())
                 with open(os.path.join(csrc, f), "rb") as fh:
                     h.update(fh.read())

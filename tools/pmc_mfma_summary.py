@@ -28,7 +28,7 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))
     if gui <= 0:
         continue
     rows.append(dict(kernel=k, launches=n[k], gui_active_sum=gui, mfma_busy_cycles=mf, mfma_busy=round(mf / (gui / 8 * 1024), 4)))
-g = [r for r in rows if "gemm_bf16_kernel" in r["kernel"] or "gemm_stream_kernel" in r["kernel"]]
+g = [r for r in rows if "gemm_bf16_kernel" in r["kernel"] or "gemm_stream_kernel" in r["kernel"] or "gemm_a4" in r["kernel"]]
 fam = sum(r["mfma_busy_cycles"] for r in g) / (sum(r["gui_active_sum"] for r in g) / 8 * 1024)
 json.dump(dict(note=__doc__.strip().split("\n\n")[1] if False else "see tools/pmc_mfma_summary.py for the normalisation and its check",
                command="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --tower-streams 1",

@@ -44,7 +44,7 @@ def main():
         n, kb = fe[k]
         wn, wkb = wr.get(k, (0, 0.0))
         rows.append(dict(kernel=k, launches=n, fetch_kb_per_launch_raw=kb / n, write_kb_per_launch=(wkb / wn if wn else None)))
-    g = [r for r in rows if "gemm_bf16_kernel" in r["kernel"] or "gemm_stream_kernel" in r["kernel"]]
+    g = [r for r in rows if "gemm_bf16_kernel" in r["kernel"] or "gemm_stream_kernel" in r["kernel"] or "gemm_a4" in r["kernel"]]
     gl = sum(r["launches"] for r in g)
     gf = sum(r["fetch_kb_per_launch_raw"] * r["launches"] for r in g) / gl * 1e3 / 1e6              # MB / launch, raw
     gw = sum((r["write_kb_per_launch"] or 0) * r["launches"] for r in g) / gl * 1e3 / 1e6

@@ -28,6 +28,13 @@ def table(tag, stats_csv, traffic_json, mfma_json, steps):
               if mb is not None else f"| `{k}` | {calls / steps:.0f} | {avg:.1f} | {pct:.1f} | - | - | - | {mf.get(k, float('nan')):.3f} |")
 
 
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "r03":
+    table("Round 3 - encode_image, ViT-B/32 bs 1024 bf16, batch whole on ONE stream (CCLIP_IMAGE_LANES=1; 25 passes under the profiler)",
+          "r03_image_single_kernel_stats.csv", "r03_image_bs1024_hbm_traffic_pmc.json", "r03_image_bs1024_mfma_busy_pmc.json", 25)
+    table("Round 3 - train step, ViT-B/32 bs 1024 bf16, packed text rows, single stream (10 steps under the profiler: 2 warm-up + 6 timed + 2 roofline-leg)",
+          "r03_train_single_kernel_stats.csv", "r03_train_bs1024_hbm_traffic_pmc.json", "r03_train_bs1024_mfma_busy_pmc.json", 10)
+    sys.exit(0)
 table("Train step, ViT-B/32 bs 1024 bf16, single stream (10 steps under the profiler: 2 warm-up + 6 timed + 2 roofline-leg)",
       "r02_train_single_kernel_stats.csv", "r02_train_bs1024_hbm_traffic_pmc.json", "r02_train_bs1024_mfma_busy_pmc.json", 10)
 table("BASELINE configs[3]: caption train step (MLP mapper + GPT-2-small, V = 21128, bs 256, S = 80), 8 steps under the profiler",
