@@ -47,7 +47,7 @@ def timed(n=8):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-class Logged(dict):
+class Logged(ops._GenDict):
     seen = []
 
     def get(self, k, d=None):
@@ -70,7 +70,7 @@ changed = {}
 for k in keys:
     cur = logged[k]
     best, best_t = cur, base
-    for cfg in (1, 2, 3, 4, 5, 7):
+    for cfg in (1, 2, 3, 4, 5, 7, 8):
         if cfg == cur[0]:
             continue
         logged[k] = (cfg, 1)
@@ -120,5 +120,5 @@ for k in wkeys:
 print("changed:", json.dumps({k: [list(v[0]), list(v[1]), round(v[2], 3), round(v[3], 3)] for k, v in changed.items()}, indent=1))
 print(f"final {min(timed(), timed()):.3f} ms")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-ops._TUNED = dict(logged)
+ops._TUNED = ops._GenDict(logged)
 ops.save_tuned_table(os.path.join(ROOT, "gpurun_out", "gemm_tune_step.json"))
