@@ -8,6 +8,7 @@ per MFMA x 16 = 1.73e10 vs 1.749e10 counted).  GRBM_GUI_ACTIVE comes back summed
     mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)
 = the fraction of SIMD-cycles with the matrix pipe busy while the kernel ran (clock-independent, unlike TFLOP/s vs the 2.4 GHz peak).
 """
+import os
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -31,7 +32,7 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))
 g = [r for r in rows if "gemm_bf16_kernel" in r["kernel"] or "gemm_stream_kernel" in r["kernel"] or "gemm_a4" in r["kernel"]]
 fam = sum(r["mfma_busy_cycles"] for r in g) / (sum(r["gui_active_sum"] for r in g) / 8 * 1024)
 json.dump(dict(note=__doc__.strip().split("\n\n")[1] if False else "see tools/pmc_mfma_summary.py for the normalisation and its check",
-               command="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --tower-streams 1",
+               command="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- " + os.environ.get("PMC_BENCH_COMMAND", "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --tower-streams 1"),
                **provenance(),
                gemm_family_mfma_busy=round(fam, 4), kernels=rows[:30]), open(out, "w"), indent=1)
 print("GEMM family MFMA-busy:", round(fam, 4))

@@ -7,6 +7,7 @@ Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 
 on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads -> x2 (calibration: colsum_partial reads its input
 exactly once and reports half of it raw).  The counters sit at the L2 <-> fabric boundary: Infinity-Cache hits are included.
 """
+import os
 import csv, glob, json, os, subprocess, sys
 from collections import defaultdict
 
@@ -50,7 +51,7 @@ def main():
     gw = sum((r["write_kb_per_launch"] or 0) * r["launches"] for r in g) / gl * 1e3 / 1e6
     json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 --no-cpu-baseline; "
                         "FETCH_SIZE raw is in KB; gfx950 reports half the bytes of wide coalesced reads -> x2 (MI355X_MICROARCH.md)",
-                   command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --tower-streams 1",
+                   command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- " + os.environ.get("PMC_BENCH_COMMAND", "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --tower-streams 1"),
                    **provenance(), kernels=rows[:40],
                    gemm_family=dict(launches=gl, fetch_mb_per_launch_raw=gf, fetch_mb_per_launch_corrected=2 * gf, write_mb_per_launch=gw)),
               open(out, "w"), indent=1)

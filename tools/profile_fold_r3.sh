@@ -15,8 +15,10 @@ stats() { cp "$(ls -t $1/*/*kernel_stats.csv | head -1)" $P/$2; }
 line() { grep '^{"metric"' $1 | tail -1 > $P/$2; }
 stats $OI/image_lanes r03_image_lanes_kernel_stats.csv;   line $OI/image_lanes.log r03_bench_image_lanes_under_rocprof.json
 stats $OI/image_single r03_image_single_kernel_stats.csv; line $OI/image_single.log r03_bench_image_single_under_rocprof.json
+export PMC_BENCH_COMMAND='CCLIP_IMAGE_LANES=1 python3 bench.py --no-cpu-baseline --no-extras --mode image --steps 2 --warmup 1'
 python tools/pmc_summary.py $OI/image_fetch $OI/image_write $P/r03_image_bs1024_hbm_traffic_pmc.json
 python tools/pmc_mfma_summary.py $OI/image_mfma $P/r03_image_bs1024_mfma_busy_pmc.json
+unset PMC_BENCH_COMMAND
 stats $OT/train_default r03_train_default_kernel_stats.csv; line $OT/train_default.log r03_bench_train_default_under_rocprof.json
 stats $OT/train_single r03_train_single_kernel_stats.csv;   line $OT/train_single.log r03_bench_train_single_under_rocprof.json
 python tools/pmc_summary.py $OT/train_fetch $OT/train_write $P/r03_train_bs1024_hbm_traffic_pmc.json
