@@ -91,6 +91,10 @@ typedef struct cclip_gemm_desc {
                         * 10 = configuration 8 as a persistent kernel (one work-group per CU walks tiles, the next tile's first operands
                         *     are staged during the current tile's last iteration); K >= 192.  Not an autotuner candidate: next to a
                         *     second stream's kernels it loses to configuration 8 (it holds every CU for its whole life).
+                        * 11 = the WEIGHT-GRADIENT layout (a_kcontig = b_kcontig = 0: both operands strided in K) on four 128x128 waves
+                        *     with a hand-scheduled K loop (transposing LDS reads; tools/gen_gemm_a4.py), split-K, fused colsum_out
+                        *     (of A; colsum_of_b is refused); M, N multiples of 8, K % 64 == 0 and at least two 64-deep K-tiles per
+                        *     split (callers keep activation / gradient slabs on 64-row multiples with zero tails); status 1 otherwise.
                         * The host-side autotuner (cclip_hip/ops.py) times the configurations per shape. */
   /* wgrad layout (0,0) only: colsum_out[m] (+)= sum_k A(m,k) - the BIAS gradient of the layer whose weight gradient this
    * call computes (A = dY^T), taken off the operand tiles already in LDS by one extra MFMA per m-tile against an all-ones
