@@ -106,7 +106,7 @@ def main(argv=None):
             opt.step()
             sched.step()
             step += 1
-            C.log_line(epoch=epoch, step=step, loss=round(float(loss), 6))
+            C.log_line(epoch=epoch, step=step, loss=round(float(loss.detach()), 6))
             if args.max_steps and step >= args.max_steps:
                 break
         if epoch % args.save_every == 0 or epoch == args.epochs - 1:                      # train.py:377-381

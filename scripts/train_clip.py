@@ -101,7 +101,7 @@ def main(argv=None):
             opt.step()
             sched.step()
             step += 1
-            C.log_line(epoch=epoch, step=step, loss=round(float(loss), 6), accuracy=round(acc, 4), lr=sched.get_last_lr()[0])
+            C.log_line(epoch=epoch, step=step, loss=round(float(loss.detach()), 6), accuracy=round(acc, 4), lr=sched.get_last_lr()[0])
             if args.max_steps and step >= args.max_steps:
                 break
         test_acc = evaluate(model, test_dl, device)
