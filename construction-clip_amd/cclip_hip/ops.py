@@ -887,34 +887,16 @@ def embed_scatter_tables(text_i32, V: int, *, rows: int, keep: Optional[torch.Te
     """Index tables of the deterministic embedding-gradient sum (see embed_scatter_add): the row list sorted by token id
     (stable) and, per sorted position, the chunk / run bookkeeping csrc/embed.hip walks.  Integer math on a [rows] vector that
     depends on the token ids only - a training step can build it while the forward pass runs (clip/model.py does, on a side
-    stream: ~25 small launches incl. a sort and three scans, 1.2 ms when issued in the backward pass)."""
-    dev = text_i32.device
+    stream).  The sort is the device library's; the tables come from one scan-free kernel (cclip_embed_tables: two binary
+    searches per position; round 2 built them from ~25 small torch launches incl. three single-block scans, 0.6 ms)."""
     tok = text_i32[:rows].clamp(0, V - 1)
     if keep is not None:                                  # dropped rows sort to the end under a sentinel id and form no chunk
         tok = torch.where(keep[:rows], tok, torch.full_like(tok, V))
-    n = rows
-    st, perm = torch.sort(tok, stable=True)
+    st, perm = torch.sort(tok.to(torch.int32), stable=True)
     order = perm.to(torch.int32)
-    pos = torch.arange(n, device=dev, dtype=torch.int32)
-    valid = st < V
-    new_run = torch.ones(n, device=dev, dtype=torch.bool)
-    new_run[1:] = st[1:] != st[:-1]
-    nbig = torch.full((1,), n, device=dev, dtype=torch.int32)
-
-    def next_marked_after(mark):                          # for every p: the first q > p with mark[q], or n
-        at = torch.where(mark, pos, nbig.expand(n))
-        ge = torch.flip(torch.cummin(torch.flip(at, (0,)), 0).values, (0,))       # first q >= p
-        return torch.cat((ge[1:], nbig))
-
-    run_start_of = torch.cummax(torch.where(new_run, pos, torch.zeros_like(pos)), 0).values     # start of p's run
-    new_chunk = (new_run | (((pos - run_start_of) % _SEG_CHUNK) == 0)) & valid
-    cend = torch.where(new_chunk, next_marked_after(new_chunk | ~valid), torch.zeros_like(pos))
-    cidx = torch.cumsum(new_chunk.to(torch.int32), 0).to(torch.int32) - 1
-    nxt_run = next_marked_after(new_run)
-    total = cidx[-1:] + 1
-    cidx_at_next = torch.where(nxt_run < n, cidx[nxt_run.clamp(max=n - 1).long()] + (~new_chunk[nxt_run.clamp(max=n - 1).long()]).to(torch.int32), total.expand(n))
-    rlen = torch.where(new_run & valid, cidx_at_next - cidx, torch.zeros_like(pos)).to(torch.int32)
-    return (order.contiguous(), st.contiguous(), cend.to(torch.int32).contiguous(), cidx.contiguous(), rlen.contiguous())
+    tabs = torch.empty((3, rows), device=text_i32.device, dtype=torch.int32)
+    check(lib.cclip_embed_tables(_p(st), c_int(rows), c_int(V), _p(tabs[0]), _p(tabs[1]), _p(tabs[2]), _stream()), "cclip_embed_tables")
+    return (order, st, tabs[0], tabs[1], tabs[2])
 
 
 def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None, seq_stride: Optional[int] = None,
@@ -936,10 +918,10 @@ def embed_scatter_add(text_i32, dx, demb, *, rows: int, L: Optional[int] = None,
     V, D = demb.shape
     order, st, cend, cidx, rlen = tables if tables is not None else embed_scatter_tables(text_i32, V, rows=rows, keep=keep)
     n = rows
-    # one slot per CHUNK (a run of <= 64 equal ids), touched by multi-chunk runs only: at most one chunk per distinct id plus one
-    # per 64 rows.  `scratch(n_floats)` (the stack's grow-only scratch) keeps it out of the allocator: round 2 drew a fresh
-    # [rows, D] fp32 tensor - 161 MB at bs 1024 - per backward pass.
-    slots = min(n, V + n // _SEG_CHUNK + 1)
+    # one slot per CHUNK (a run of <= 64 equal ids), touched by multi-chunk runs only; slot = id + (chunk start >> 6)
+    # (cclip_embed_tables).  `scratch(n_floats)` (the stack's grow-only scratch) keeps it out of the allocator: round 2 drew a
+    # fresh [rows, D] fp32 tensor - 161 MB at bs 1024 - per backward pass.
+    slots = V + n // _SEG_CHUNK + 1
     partial = scratch(slots * D) if scratch is not None else torch.empty(slots * D, device=text_i32.device, dtype=torch.float32)
     check(lib.cclip_embed_segsum(_p(order), _p(st), _p(cend), _p(cidx), _p(rlen), c_int(n), _p(dx), c_long(dx.stride(-2)), c_int(D),
                                  _p(demb), c_int(L), c_int(seq_stride), c_int(seq_off), _p(partial), _stream()), "cclip_embed_segsum")

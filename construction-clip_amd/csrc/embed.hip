@@ -233,6 +233,28 @@ __global__ __launch_bounds__(256) void embed_segsum_finish_kernel(const int* __r
   }
 }
 
+// The chunk / run tables embed_segsum_kernel walks, from the SORTED id list alone and without a scan: a position finds the ends of
+// its run of equal ids by two binary searches of the (L2-resident) list, and a chunk's partial slot is id + (chunk start >> 6) -
+// strictly increasing over chunk starts (ids are non-decreasing, chunk starts of one id are 64 apart), consecutive within a run,
+// and below V + n/64 + 1.  Ids >= V (rows dropped up front: they sort to the end) form no chunk.
+__global__ __launch_bounds__(256) void embed_tables_kernel(const int* __restrict__ st, int n, int V, int* __restrict__ cend,
+                                                           int* __restrict__ cidx, int* __restrict__ rlen) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int t = st[p];
+  int lo = 0, hi = p;                                  // first position holding t
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (st[mid] < t) lo = mid + 1; else hi = mid; }
+  const int rs = lo;
+  lo = p + 1; hi = n;                                  // first position past the run
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (st[mid] <= t) lo = mid + 1; else hi = mid; }
+  const int re = lo;
+  const bool valid = t < V;
+  const bool chunk_start = valid && (((p - rs) & 63) == 0);
+  cend[p] = chunk_start ? (p + 64 < re ? p + 64 : re) : 0;
+  cidx[p] = valid ? t + (p >> 6) : 0;
+  rlen[p] = (valid && p == rs) ? (re - rs + 63) >> 6 : 0;
+}
+
 // GPT-2 input rows for the prefix-caption model (CLIP_prefix_caption/train.py:258-263):
 //   x[b, s] = (s < P ? prefix_proj[b, s] : wte[ids[b, s - P]]) + wpe[s]
 __global__ __launch_bounds__(256) void caption_embed_kernel(const float* __restrict__ prefix_proj, const int* __restrict__ ids,
@@ -398,6 +420,15 @@ extern "C" int cclip_embed_segsum(const int32_t* order, const int32_t* tok_sorte
   hipLaunchKernelGGL(embed_segsum_kernel, dim3(grid_rows4(n)), dim3(256), 0, stream, order, tok_sorted, cend, cidx, rlen, n, dx,
                      (long)lddx, D, demb, L, seq_stride, seq_off, partial);
   hipLaunchKernelGGL(embed_segsum_finish_kernel, dim3(grid_rows4(n)), dim3(256), 0, stream, tok_sorted, cidx, rlen, n, partial, D, demb);
+  return cclip_launch_status();
+}
+#endif
+
+#ifndef CCLIP_F16
+extern "C" int cclip_embed_tables(const int32_t* tok_sorted, int32_t n, int32_t V, int32_t* cend, int32_t* cidx, int32_t* rlen,
+                                  hipStream_t stream) {
+  if (!tok_sorted || !cend || !cidx || !rlen || n <= 0 || V <= 0) return CCLIP_ERR_ARG;
+  hipLaunchKernelGGL(embed_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, tok_sorted, n, V, cend, cidx, rlen);
   return cclip_launch_status();
 }
 #endif

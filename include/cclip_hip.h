@@ -222,9 +222,13 @@ int cclip_embed_scatter_add(const int32_t* text, const float* dx, int64_t lddx, 
                             hipStream_t stream);
 /* Deterministic form of the same sum (no atomics).  `order` lists the n rows sorted by token id (stable), tok_sorted their ids;
  * per list position p: cend[p] > 0 marks the start of a CHUNK (at most 64 rows of one id) ending at cend[p], cidx[p] is the
- * chunk index (= its slot in `partial`, [n, D] floats), rlen[p] > 0 marks the start of a run of equal ids made of rlen[p] chunks.
+ * chunk's slot in `partial`, rlen[p] > 0 marks the start of a run of equal ids made of rlen[p] chunks.
  * One-chunk runs are added into demb[id] by the wave that owns them, longer runs through ordered partials (two launches).
- * All tables are fixed-size index vectors: the caller needs no host synchronisation.  Bit-identical from run to run. */
+ * All tables are fixed-size index vectors: the caller needs no host synchronisation.  Bit-identical from run to run.
+ * cclip_embed_tables builds cend / cidx / rlen from tok_sorted alone (ids >= V = rows dropped up front, sorted to the end):
+ * chunk slots are id + (chunk start >> 6), so `partial` holds (V + n/64 + 1) * D floats. */
+int cclip_embed_tables(const int32_t* tok_sorted, int32_t n, int32_t V, int32_t* cend, int32_t* cidx, int32_t* rlen,
+                       hipStream_t stream);
 int cclip_embed_segsum(const int32_t* order, const int32_t* tok_sorted, const int32_t* cend, const int32_t* cidx,
                        const int32_t* rlen, int32_t n, const float* dx, int64_t lddx, int32_t D, float* demb, int32_t L,
                        int32_t seq_stride, int32_t seq_off, float* partial, hipStream_t stream);

@@ -283,6 +283,44 @@ def test_embedding_gradient_is_deterministic_and_handles_long_runs():
     close("segsum gpt2 rows", d3, ref3.float(), 1e-5, 1e-4)
 
 
+@pytest.mark.parametrize("n,V,drop", [(64 * 77, 500, 0.25), (1000, 49408, 0.0), (5000, 7, 0.5), (65, 3, 0.0), (1, 10, 0.0)])
+def test_embedding_gradient_tables(n, V, drop):
+    """cclip_embed_tables (csrc/embed.hip): chunk / run bookkeeping of the sorted id list from binary searches - against a plain
+    host walk of the same list: every run of a kept id is cut into chunks of <= 64 rows, a chunk start carries its end, a run
+    start its chunk count, chunk slots are unique, consecutive inside a run and below V + n/64 + 1; dropped rows form no chunk."""
+    o = ops()
+    g = G(n + V)
+    text = torch.randint(0, V, (n,), device="cuda", generator=g, dtype=torch.int32)
+    if n > 100:
+        text[::3] = V // 2                                              # a hot id: runs of many chunks
+    keep = (torch.rand(n, device="cuda", generator=g) >= drop) if drop else None
+    order, st, cend, cidx, rlen = o.embed_scatter_tables(text, V, rows=n, keep=keep)
+    tok = text.cpu().tolist(); kp = keep.cpu().tolist() if keep is not None else [True] * n
+    key = [t if k else V for t, k in zip(tok, kp)]
+    want_order = sorted(range(n), key=lambda r: (key[r], r))
+    assert order.cpu().tolist() == want_order
+    stl = [key[r] for r in want_order]
+    assert st.cpu().tolist() == stl
+    ce, ci, rl = cend.cpu().tolist(), cidx.cpu().tolist(), rlen.cpu().tolist()
+    p, slots = 0, set()
+    while p < n:
+        q = p
+        while q < n and stl[q] == stl[p]:
+            q += 1
+        if stl[p] >= V:                                                  # dropped rows
+            assert all(ce[i] == 0 and rl[i] == 0 for i in range(p, q))
+        else:
+            k = (q - p + 63) // 64
+            assert rl[p] == k and all(rl[i] == 0 for i in range(p + 1, q))
+            for j in range(k):
+                c = p + 64 * j
+                assert ce[c] == min(c + 64, q)
+                assert ci[c] == ci[p] + j and ci[c] not in slots and 0 <= ci[c] < V + n // 64 + 1
+                slots.add(ci[c])
+            assert all(ce[i] == 0 for i in range(p, q) if (i - p) % 64)
+        p = q
+
+
 @pytest.mark.parametrize("R,C,bf", [(1000, 768, True), (50, 2304, False), (4097, 104, True), (300, 100, False)])
 def test_colsum(R, C, bf):
     o = ops()
