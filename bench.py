@@ -411,6 +411,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="train mode: skip the extra encode_image / forward-only / fp16-operand legs timed after the headline steps")
+    ap.add_argument("--text-prefetch", action="store_true",
+                    help="announce the next token batch one step ahead (model.prefetch_text) instead of reading the packed text tower's row count "
+                         "back at the start of the step; measured SLOWER (51.6-51.7 vs 50.8 ms, DESIGN.md 6.0) and therefore off")
     ap.add_argument("--model", default="ViT-B/32")
     ap.add_argument("--dtype", choices=["bf16", "fp16", "fp8"], default="bf16",
                     help="MFMA operand type; fp8 = e4m3 projections of the image tower's blocks (inference modes only; CCLIP_FP8_WIDE=0: qkv / fc only), bf16 elsewhere")
@@ -454,8 +457,19 @@ def main():
 
     os.environ["CCLIP_TOWER_STREAMS"] = str(args.tower_streams)
 
+    # --text-prefetch: a training loop holds batch k+1 while step k runs; it can announce that batch's token ids
+    # (model.prefetch_text) BEFORE it launches step k, and the packed text tower then finds its live-row count in pinned memory
+    # instead of reading it back at the start of the step.  Two copies of the synthetic token batch alternate so that the
+    # announcement really is one step ahead of the use.  Default: one blocking read per step.
+    texts = [text, text.clone()] if args.text_prefetch else [text]
+    turn = [0]
+
     def encode_both():
-        return model.encode_image_text(image, text)
+        t = texts[turn[0] % len(texts)]
+        if len(texts) > 1:
+            model.prefetch_text(texts[(turn[0] + 1) % len(texts)])
+        turn[0] += 1
+        return model.encode_image_text(image, t)
 
     def step():
         if args.mode == "image":
@@ -574,6 +588,7 @@ def main():
             packed = model._pack_text_rows()
             out["config"]["text_rows"] = {
                 "context_length": geo.context_length, "rows_dense": B * geo.context_length, "rows_live": live, "packed": packed,
+                "row_count_prefetched": bool(packed and args.text_prefetch),   # model.prefetch_text one batch ahead (no mid-step read-back)
                 "note": "captions end at their EOT token (position uniform in [2, 76], SURVEY.md 8d); the causal text tower pools the EOT "
                         "row, so later positions influence neither features nor gradients" + (
                             " - it runs on the live rows only, sequences back to back (CCLIP_PACK_TEXT=0: all 77 positions)" if packed

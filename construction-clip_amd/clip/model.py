@@ -353,6 +353,43 @@ class CLIP(nn.Module):
         ar.publish_grads(self._rt["vis_names"])
 
     # -- text tower -----------------------------------------------------------------------------
+    def prefetch_text(self, text: torch.Tensor) -> None:
+        """Tell the model about a token batch BEFORE the step that consumes it is launched (a training loop calls this on batch
+        k+1, then launches step k).  The packed text tower sizes its launches by the batch's live-row count; this computes the
+        count on a helper stream and mails it to pinned host memory, so the consuming call finds it there instead of draining
+        the device queue for it (`.item()` in the middle of a step: the host cannot run ahead of the device across steps).
+        Optional: a batch that was not announced is counted with one blocking read, as before.  Keyed by the tensor's storage,
+        version and shape - pass the SAME tensor object to the model afterwards."""
+        if text.device.type != "cuda" or text.dim() != 2 or text.shape[0] < 2:
+            return
+        hints = self.__dict__.setdefault("_text_hints", {})
+        key = (text.data_ptr(), text._version, tuple(text.shape))
+        if key in hints:
+            return
+        side = self.__dict__.get("_hint_stream")
+        if side is None:
+            side = self.__dict__["_hint_stream"] = torch.cuda.Stream(device=text.device)
+        box = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            total = (text.detach().argmax(dim=-1) + 1).sum().reshape(1)
+            box.copy_(total, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        text.record_stream(side)
+        hints[key] = (box, ev, total)
+        while len(hints) > 8:                                   # a handful of batches ahead at most
+            hints.pop(next(iter(hints)))
+
+    def _live_text_rows(self, text: torch.Tensor, eot: torch.Tensor) -> int:
+        """sum(eot + 1): from prefetch_text's mailbox when the batch was announced, else one blocking read."""
+        hint = self.__dict__.get("_text_hints", {}).pop((text.data_ptr(), text._version, tuple(text.shape)), None)
+        if hint is not None:
+            box, ev, _ = hint
+            ev.synchronize()                                    # recorded a step ago: normally long complete
+            return int(box[0])
+        return int((eot + 1).sum().item())
+
     def _text_forward(self, text: torch.Tensor, train: bool):
         self._ensure_runtime()
         ar, geo, st = self._arena, self.geo, self._rt["txt"]
@@ -379,21 +416,21 @@ class CLIP(nn.Module):
         # 0..eot_b - the tower is causal and only the EOT row is pooled, so later rows influence neither the features nor any
         # gradient (their upstream gradient is exactly zero).  The tower runs on the sum(eot_b + 1) live rows, sequences back
         # to back (cu = their row ranges), instead of on B*77: the same features and gradients (the weight gradients' sums lose
-        # only exact-zero terms) at about half the rows for captions of uniformly distributed length.  Costs one device->host
-        # sync per call (the row count sizes every launch); the embedding stays dense - its live rows are gathered in,
-        # and their gradients scattered back, by two index copies.
+        # only exact-zero terms) at about half the rows for captions of uniformly distributed length.  The row count sizes
+        # every launch, so the host must know it: from prefetch_text's mailbox (no queue drain) or one blocking read; the
+        # embedding stays dense - its live rows are gathered in, and their gradients scattered back, by two index copies.
         rowmap = cu = None
         # (the packed attention kernels hold one sequence per work-group: head_dim 64, <= 128 positions; other geometries run dense)
         if (self._pack_text_rows() and B > 1 and st.geo.head_dim == 64 and L <= 128
                 and not torch.cuda.is_current_stream_capturing()):
-            live = torch.arange(L, device=dev)[None, :] <= eot[:, None]
-            rowmap = live.reshape(-1).nonzero().squeeze(1)                    # packed row -> dense row b*L + t (the sync)
-            Mp = int(rowmap.numel())
+            Mp = self._live_text_rows(text, eot)                              # the one host-side number: it sizes every launch
             if Mp < M:
                 cu = torch.zeros(B + 1, device=dev, dtype=torch.int32)
                 cu[1:] = torch.cumsum(eot + 1, 0)
-            else:
-                rowmap = None
+                # packed row j -> dense row b*L + t: b = the sequence whose range [cu[b], cu[b+1]) holds j (index math, no sync)
+                j = torch.arange(Mp, device=dev, dtype=torch.int32)
+                b = torch.searchsorted(cu[1:], j, right=True)
+                rowmap = b * L + (j - cu[b]).long()
         xd = torch.empty(M, D, device=dev, dtype=torch.float32) if (cu is not None or not train) else None
         if cu is not None:
             saved = st.alloc_saved(B, dev, T=L, M=Mp) if train else None

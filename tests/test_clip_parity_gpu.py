@@ -447,6 +447,43 @@ def test_packed_text_rows_equal_dense_rows(dtype):
             assert torch.equal(o[3]["positional_embedding"][top:], torch.zeros_like(o[3]["positional_embedding"][top:]))
 
 
+def test_announced_token_batch_gives_the_same_packed_run():
+    """model.prefetch_text: the packed tower's live-row count mailed to pinned memory one batch ahead.  Same features and
+    gradients bit for bit as the unannounced call (one blocking read), the announcement is consumed by the call that uses it,
+    and a batch edited in place after its announcement is counted afresh (the key holds the tensor's version)."""
+    import clip
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    geo = MODELS["test-small"]
+    B = 8
+    img = synthetic_images(B, geo, 1).cuda()
+    txt = synthetic_text(B, geo, 2).cuda()
+    runs = []
+    for announce in (False, True):
+        model = clip.build_model(init_state_dict(geo, 7), torch.bfloat16).cuda().train()
+        if announce:
+            model.prefetch_text(txt)
+            assert len(model._text_hints) == 1
+        li, lt = model(img, txt)
+        _ce(li, lt).backward()
+        if announce:
+            assert len(model._text_hints) == 0
+        runs.append((li.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+    # announced, then edited in place: the stale count must not be used (a shorter batch would index past its rows)
+    model.eval()
+    t2 = txt.clone()
+    model.prefetch_text(t2)
+    eot = int(t2[0].argmax())
+    t2[0, eot] = 0
+    t2[0, 1] = t2.max()                                       # caption 0 now ends at position 1
+    with torch.no_grad():
+        a = model.encode_text(t2)
+        b = model.encode_text(t2.clone())
+    assert torch.equal(a, b)
+
+
 def test_image_lanes_are_bit_identical_to_the_whole_batch(monkeypatch):
     """Inference on a large batch runs as two half batches on two HIP streams (clip/model.py:_image_forward_lanes): the same
     features bit for bit as the whole batch on one stream, for an odd batch size too (encode_image_text keeps the image batch whole:

@@ -10,7 +10,8 @@ cfgs = [int(a) for a in argv] or [3, 7, 8]
 Mi, Mt = 51200, 78848
 shapes = [("img out res", Mi, 768, 768, "res"), ("img proj res", Mi, 768, 3072, "res"), ("img fc gelu+pre", Mi, 3072, 768, "gelu"),
           ("img dproj dact", Mi, 3072, 768, "dact"), ("txt fc gelu+pre", Mt, 2048, 512, "gelu"), ("txt dproj dact", Mt, 2048, 512, "dact"),
-          ("txt proj res", Mt, 512, 2048, "res")]
+          ("txt proj res", Mt, 512, 2048, "res"),
+          ("img fc gelu (inf)", Mi, 3072, 768, "geluinf"), ("lane fc gelu (inf)", Mi // 2, 3072, 768, "geluinf"), ("img fc bare", Mi, 3072, 768, "bf16")]
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, M, N, K, kind in shapes:
     ds = [G.desc(M, N, K, 1, 1, kind, c, 1) for c in cfgs]

@@ -28,9 +28,11 @@ def desc(M, N, K, akc, bkc, kind, cfg, split):
     d.A, d.B, d.a_kcontig, d.b_kcontig, d.lda, d.ldb = A.data_ptr(), B.data_ptr(), akc, bkc, A.stride(0), B.stride(0)
     d.M, d.N, d.K, d.alpha, d.ldc, d.split_k, d.tile_config = M, N, K, 1.0, N, 1, cfg
     bias = torch.randn(N, device="cuda"); keep.append(bias)
-    if kind in ("bf16", "gelu", "res", "dact"):
+    if kind in ("bf16", "gelu", "geluinf", "res", "dact"):
         d.bias = bias.data_ptr()
-    if kind in ("bf16", "gelu", "dact"):
+    if kind == "geluinf":                                  # inference fc: QuickGELU, 16-bit output only
+        d.act = 1
+    if kind in ("bf16", "gelu", "geluinf", "dact"):
         o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); keep.append(o); d.out_bf16 = o.data_ptr()
     if kind == "gelu":
         o2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); keep.append(o2); d.out_pre_bf16 = o2.data_ptr(); d.act = 1
