@@ -219,12 +219,14 @@ def _nearest_tuned(key: str, unbounded: bool = False):
     if best is None:
         return None
     cfg, sp = vals[best]
+    cfg, order = cfg & 255, cfg & ~255      # (bits 8..15: the tile order's column-group width, kept)
     if cfg in (4, 8, 10) and tok == 1:
         kk = int(key.split("|")[3])
         if cfg == 4 and want % 256:
             cfg = 3           # the persistent streaming configuration covers full 256-row tiles only
         if cfg in (8, 10) and (kk % 64 or kk < 192):
             cfg = 3           # the hand-scheduled configurations need whole 64-deep K-tiles
+    cfg |= order
     if tok == 3 and sp > 1:
         sp = max(1, min(sp, round(sp * want / toks[best])))
     if tok == 3 and cfg == 11 and (want % 64 or want // 64 < 2 * sp):
@@ -455,6 +457,10 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kco
                 _TUNE_STATE["derived"] = _TUNE_STATE.get("derived", 0) + 1
         if choice is None:
             cands = split_candidates if split_candidates is not None else [(c, split_k) for c in (1, 2, 3, 4, 5, 7, 8)]
+            if split_candidates is None and a_kcontig and b_kcontig and split_k == 1:
+                # the 256-wide configurations again with the column tiles taken in groups of g (tile_config bits 8..15): which
+                # weight panels one XCD's L2 holds together - decided by timing, like the tile itself
+                cands += [(c + 256 * g, split_k) for c in (3, 8) for g in (3, 4, 6) if (N + 255) // 256 > g]
             if split_candidates is None and split_k > 1:
                 d.split_ws = split_ws.data_ptr()
             choice = _autotune(d, key, outs3, cands)

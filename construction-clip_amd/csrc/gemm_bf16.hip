@@ -163,7 +163,10 @@ extern "C" int CCLIP_GEMM_FN(const cclip_gemm_desc* d, hipStream_t stream) {
 
   { static const int dbg = getenv("CCLIP_GEMM_DBG") ? atoi(getenv("CCLIP_GEMM_DBG")) : 0; a.dbg = dbg; }
   a.ln_stats = d->ln_stats; a.ln_c1 = d->ln_c1; a.rowstats = d->rowstats_out;
-  int cfg = d->tile_config;
+  int cfg = d->tile_config & 255;
+  a.group_n = (d->tile_config >> 8) & 255;          // column-group width of the tile order (tile_coords); 0 = row-major
+  if (d->tile_config < 0 || (d->tile_config >> 16)) return CCLIP_ERR_ARG;
+  if (a.group_n && (cfg == 0 || cfg == 4 || cfg == 10 || cfg == 11)) return CCLIP_ERR_ARG;   // those walk tiles their own way
   if (a.ln_stats || a.ln_c1 || a.rowstats) {        // the folded-LayerNorm forms: configuration 8, whole 256x256 tiles only
     if (cfg != 8 || (d->M & 255) || (d->N & 255) || splits > 1 || !d->a_kcontig || !d->b_kcontig) return CCLIP_ERR_ARG;
     if ((a.ln_stats == nullptr) != (a.ln_c1 == nullptr)) return CCLIP_ERR_ARG;

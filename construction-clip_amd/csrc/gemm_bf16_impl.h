@@ -35,6 +35,7 @@ struct GemmArgs {
   // configurations 8 / 10: LayerNorm folded into the projection (cclip_hip.h): (mean, rstd) per row, column sums of the scaled weight;
   // the residual form's extra outputs for the next folded projection
   const float* ln_stats = nullptr; const float* ln_c1 = nullptr; float* rowstats = nullptr;
+  int group_n = 0;    // tile order: 0 = row-major over (row tile, column tile); G > 0 = column groups of G tiles, row-major inside a group (tile_coords)
   int dbg = 0;        // timing ablations of configurations 8 / 10 (CCLIP_GEMM_DBG; bit 0: no epilogue) - never set by the product path
 };
 
@@ -46,6 +47,20 @@ struct GemmArgs {
 __device__ __forceinline__ int nperm(int nt, int i) {
   return 8 * (i >> 2) + 32 * (nt >> 1) + 4 * (nt & 1) + (i & 3);
 }
+// Work-item -> tile.  Consecutive work-items run at the same time on one XCD (xcd_remap), so the order decides which operand
+// panels that XCD's L2 holds together.  Row-major (gn = 0): a run of tiles covers few row panels x ALL column panels - right
+// while the weight is small, but a wide weight (N = 3072: 4.7 MB of 16-bit rows at K = 768, more than one XCD's 4 MB of L2) is
+// then cycled through L2 once per couple of row panels.  gn > 0: the column tiles are taken in groups of gn, all row panels of a
+// group before the next group - the XCD keeps gn weight panels hot and re-reads the activation rows once per group.
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int gn, int& tm, int& tn) {
+  if (gn <= 0 || gn >= tiles_n) { tm = bid / tiles_n; tn = bid % tiles_n; return; }
+  const int ngr = (tiles_n + gn - 1) / gn;
+  int grp = bid / (tiles_m * gn); grp = grp < ngr ? grp : ngr - 1;
+  const int r = bid - grp * tiles_m * gn;
+  const int rest = tiles_n - grp * gn, gw = rest < gn ? rest : gn;
+  tm = r / gw; tn = grp * gn + r % gw;
+}
+
 __device__ __forceinline__ int fswz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
 
 // ---- staging: an operand tile = NSUB sub-tiles of 16 KiB (128 rows/cols x 64 k); one sub-tile = 16
@@ -419,7 +434,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const GemmAr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN_ - 1) / BN_;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bm0 = (bid / tiles_n) * BM_, bn0 = (bid % tiles_n) * BN_;
+  int tm_i, tn_i;
+  tile_coords(bid, (p.M + BM_ - 1) / BM_, tiles_n, p.group_n, tm_i, tn_i);
+  const int bm0 = tm_i * BM_, bn0 = tn_i * BN_;
   const int nkt = (p.K + BK - 1) / BK;
   const int kt0 = blockIdx.y * p.ktiles_per_split;
   const int kt1 = (kt0 + p.ktiles_per_split < nkt) ? kt0 + p.ktiles_per_split : nkt;

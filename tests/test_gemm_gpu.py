@@ -205,6 +205,32 @@ def test_gemm_cfg8_epilogues(act, cfg):
             assert torch.equal(ob, ob3)
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 2304, 256), (600, 1792, 128), (300, 3072, 192)])
+@pytest.mark.parametrize("cfg", [2, 3, 8])
+@pytest.mark.parametrize("g", [3, 4, 6])
+def test_gemm_grouped_tile_order_is_bit_identical(M, N, K, cfg, g):
+    """tile_config bits 8..15: the column tiles taken in groups of g (csrc/gemm_bf16_impl.h tile_coords).  Only the ORDER in which
+    tiles are dealt to work-groups changes - every tile is computed once, by the same arithmetic: outputs equal the row-major run
+    bit for bit, including group widths that do not divide the column-tile count, ragged edge tiles, and a residual epilogue."""
+    ops = _ops()
+    g0 = torch.Generator(device="cuda").manual_seed(M + N + K + g)
+    A = (torch.randn(M, K, device="cuda", generator=g0) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device="cuda", generator=g0) * 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g0)
+    res = torch.randn(M, N, device="cuda", generator=g0)
+    outs = []
+    for tc in (cfg, cfg + 256 * g):
+        ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, bias=bias, act=1, out_bf16=ob, tile_config=tc)
+        x = res.clone()
+        ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, bias=bias, residual=x, out_f32=x, tile_config=tc)
+        outs.append((ob, x))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    _report("grouped order", outs[1][1], A.float() @ B.float().t() + bias + res, 2e-3)
+    with pytest.raises(RuntimeError):                     # configurations that walk tiles their own way refuse an order
+        ops.gemm_bf16(A, B, a_kcontig=True, b_kcontig=True, out_bf16=outs[0][0], tile_config=10 + 256 * g)
+
+
 def test_gemm_cfg8_refuses_what_it_does_not_implement():
     ops = _ops()
     A = torch.randn(256, 96, device="cuda").bfloat16()

@@ -35,13 +35,15 @@ def ours(M, N, K, akc, bkc, split):
     B = torch.randn((N, K) if bkc else (K, N), device="cuda", generator=g).bfloat16()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     best, bestcfg = 1e9, None
-    for cfg in (1, 2, 3, 4, 5, 7, 8, 10):
-        for sk in ((1,) if not split else (4, 6, 8, 12)):
+    ncol = (N + 255) // 256
+    cfgs = (1, 2, 3, 4, 5, 7, 8, 10) + tuple(c + 256 * g for c in (3, 8) for g in (3, 4, 6) if ncol > g) if not split else (2, 3, 11)
+    for cfg in cfgs:
+        for sk in ((1,) if not split else (4, 6, 7, 8, 9, 12)):
             d = GemmDesc()
             d.A, d.B, d.a_kcontig, d.b_kcontig, d.lda, d.ldb = A.data_ptr(), B.data_ptr(), akc, bkc, A.stride(0), B.stride(0)
             d.M, d.N, d.K, d.alpha, d.ldc, d.split_k, d.tile_config = M, N, K, 1.0, N, sk, cfg
             if split:
-                o = torch.empty(M, N, device="cuda"); ws = torch.empty(sk * M * N, device="cuda")
+                o = torch.empty(M, N, device="cuda"); ws = torch.empty(sk * (M * N + max(M, N)), device="cuda")
                 d.out_f32, d.split_ws = o.data_ptr(), ws.data_ptr()
             else:
                 o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); d.out_bf16 = o.data_ptr()
@@ -60,6 +62,7 @@ if __name__ == "__main__":
               ("txt proj", Mt, 512, 2048, 1, 1, 0),
               ("img wgrad qkv", 2304, 768, Mi, 0, 0, 1), ("img wgrad fc", 3072, 768, Mi, 0, 0, 1),
               ("square 4096", 4096, 4096, 4096, 1, 1, 0), ("square 8192", 8192, 8192, 8192, 1, 1, 0)]
+    print("(cfg = (tile_config, split_k); tile_config = configuration + 256 * column-group width of the tile order)")
     print(f"{'shape':16s} {'ours us':>9s} {'cfg':>8s} {'TF/s':>7s} {'frac':>6s} | {'blas us':>9s} {'TF/s':>7s} {'frac':>6s} | ours/blas")
     for name, M, N, K, akc, bkc, split in shapes:
         t, cfg, A, B = ours(M, N, K, akc, bkc, split)

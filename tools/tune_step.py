@@ -70,7 +70,8 @@ changed = {}
 for k in keys:
     cur = logged[k]
     best, best_t = cur, base
-    for cfg in (1, 2, 3, 4, 5, 7, 8):
+    ncol = (int(k.split("|")[2]) + 255) // 256
+    for cfg in (1, 2, 3, 4, 5, 7, 8) + tuple(c + 256 * g for c in (3, 8) for g in (3, 4, 6) if ncol > g):   # (+ grouped tile orders)
         if cfg == cur[0]:
             continue
         logged[k] = (cfg, 1)
