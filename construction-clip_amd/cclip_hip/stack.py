@@ -23,7 +23,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import duet, ops
 
 
 @dataclass
@@ -220,6 +220,7 @@ class BlockStack:
             xb = torch.empty(M, D, device=dev, dtype=self.dtype)   # 16-bit copy of the current stream rows (same row stride as the fp32 stream: one ldc per GEMM)
         have_stats = False                                     # stats / xb describe the CURRENT x_in (ln_1's input)?
         for l, w in enumerate(self.blocks):
+            duet.interleave_point()                            # (two towers launching side by side take turns block by block)
             if train:
                 row = bf[l]
                 xn1, qkv, a = row[:, 0:D], row[:, D:4 * D], row[:, 4 * D:5 * D]
@@ -433,6 +434,7 @@ class BlockStack:
                 fn(self._side_scratch)
 
         for l in range(L - 1, -1, -1):
+            duet.interleave_point()
             w = self.blocks[l]
             gr = w.grads
             row = bf[l]

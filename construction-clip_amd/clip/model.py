@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from cclip_hip import ops
+from cclip_hip import duet, ops
 from cclip_hip.arena import ParamArena
 from cclip_hip.stack import BlockStack, BlockWeights, Scratch, StackGeometry
 
@@ -388,7 +388,12 @@ class CLIP(nn.Module):
             box, ev, _ = hint
             ev.synchronize()                                    # recorded a step ago: normally long complete
             return int(box[0])
-        return int((eot + 1).sum().item())
+        total = (eot + 1).sum()
+        duet.pause()                                            # (launching next to the image tower: it goes on while this thread waits)
+        try:
+            return int(total.item())
+        finally:
+            duet.resume()
 
     def _text_forward(self, text: torch.Tensor, train: bool):
         self._ensure_runtime()
@@ -604,10 +609,9 @@ class CLIP(nn.Module):
         s0, s1 = self._tower_streams(image.device)
         cur = torch.cuda.current_stream()
         s0.wait_stream(cur); s1.wait_stream(cur)
-        with torch.cuda.stream(s0):
-            fi = self._image_forward(image, train=False)[0]     # (whole: the text tower is the partner here - image lanes on top measured 18.3 -> 19.4 ms)
-        with torch.cuda.stream(s1):
-            ft = self._text_forward(text, train=False)[0]
+        # (the image batch whole: the text tower is the partner here - image lanes on top measured 18.3 -> 19.4 ms)
+        (fi, _), (ft, _) = _side_by_side(image.device, s0, lambda: self._image_forward(image, train=False),
+                                         s1, lambda: self._text_forward(text, train=False))
         cur.wait_stream(s0); cur.wait_stream(s1)
         fi.record_stream(cur); ft.record_stream(cur)
         return fi, ft
@@ -626,6 +630,31 @@ class CLIP(nn.Module):
 # autograd nodes: forward = kernel sequence; backward = hand-written kernel sequence that writes the
 # arena's gradient slots directly (parameter inputs get None back; .grad is pointed at the slots).
 # ------------------------------------------------------------------------------------------------
+def _side_by_side(device, s0, f0, s1, f1):
+    """f0's launches on stream s0 and f1's on s1: f0 entirely, then f1 (default), or - CCLIP_TOWER_INTERLEAVE=1 - by two host
+    threads taking strict turns block by block (cclip_hip/duet.py), so that both streams are fed from the start.  The turns
+    matter when the host is slow next to the device (under rocprofv3 the text tower's backward started 14 ms after the image
+    tower's); on an unencumbered host the launches are far enough ahead either way: 50.10-50.14 ms in turns, 49.7-50.0 in sequence
+    (ViT-B/32 bs 1024) - hence not the default."""
+    import os
+    if os.environ.get("CCLIP_TOWER_INTERLEAVE", "0") != "1":
+        with torch.cuda.stream(s0):
+            r0 = f0()
+        with torch.cuda.stream(s1):
+            r1 = f1()
+        return r0, r1
+
+    def first():
+        with torch.no_grad(), torch.cuda.stream(s0):
+            return f0()
+
+    def second():
+        with torch.no_grad(), torch.cuda.stream(s1):
+            return f1()
+
+    return duet.run(first, second, setup_second=lambda: torch.cuda.set_device(device))
+
+
 class _ImageTower(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model: CLIP, image, *params):
@@ -665,10 +694,8 @@ class _BothTowers(torch.autograd.Function):
         s0, s1 = model._tower_streams(image.device)
         cur = torch.cuda.current_stream()
         s0.wait_stream(cur); s1.wait_stream(cur)
-        with torch.cuda.stream(s0):
-            fi, ci = model._image_forward(image, train=True)
-        with torch.cuda.stream(s1):
-            ft, ct = model._text_forward(text, train=True)
+        (fi, ci), (ft, ct) = _side_by_side(image.device, s0, lambda: model._image_forward(image, train=True),
+                                           s1, lambda: model._text_forward(text, train=True))
         cur.wait_stream(s0); cur.wait_stream(s1)
         fi.record_stream(cur); ft.record_stream(cur)
         ctx.model, ctx.ci, ctx.ct, ctx.n = model, ci, ct, len(params)
@@ -683,11 +710,14 @@ class _BothTowers(torch.autograd.Function):
         cur = torch.cuda.current_stream()
         model._arena.refresh_transposed()          # before the fork: both towers' dgrad GEMMs read the transposed shadows
         s0.wait_stream(cur); s1.wait_stream(cur)
-        if dfi is not None:
+        if dfi is not None and dft is not None:
+            dfi.record_stream(s0); dft.record_stream(s1)
+            _side_by_side(dev, s0, lambda: model._image_backward(ctx.ci, dfi), s1, lambda: model._text_backward(ctx.ct, dft))
+        elif dfi is not None:
             with torch.cuda.stream(s0):
                 dfi.record_stream(s0)
                 model._image_backward(ctx.ci, dfi)
-        if dft is not None:
+        elif dft is not None:
             with torch.cuda.stream(s1):
                 dft.record_stream(s1)
                 model._text_backward(ctx.ct, dft)

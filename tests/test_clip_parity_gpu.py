@@ -484,6 +484,42 @@ def test_announced_token_batch_gives_the_same_packed_run():
     assert torch.equal(a, b)
 
 
+def test_towers_launched_in_turns_equal_towers_launched_one_after_the_other(monkeypatch):
+    """The two towers of a training step enqueued by two host threads taking strict turns block by block (cclip_hip/duet.py,
+    CCLIP_TOWER_INTERLEAVE=1) instead of one tower after the other (default): the same kernels on the same two streams in a
+    different HOST order - logits, loss and every gradient bit for bit, over two consecutive steps (the second reuses every
+    buffer the first left behind); an exception raised inside the helper thread surfaces in the caller."""
+    import clip
+    from clip.weights import MODELS, init_state_dict, synthetic_images, synthetic_text
+    geo = MODELS["test-small"]
+    B = 8
+    img = synthetic_images(B, geo, 1).cuda()
+    txt = synthetic_text(B, geo, 2).cuda()
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CCLIP_TOWER_INTERLEAVE", mode)
+        model = clip.build_model(init_state_dict(geo, 7), torch.bfloat16).cuda().train()
+        out = []
+        for _ in range(2):
+            for p in model.parameters():
+                p.grad = None
+            li, lt = model(img, txt)
+            loss = _ce(li, lt)
+            loss.backward()
+            out.append((li.detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        with torch.no_grad():
+            fi, ft = model.encode_image_text(img, txt)
+        runs.append((out, fi, ft))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert set(a[2]) == set(b[2])
+        for n in a[2]:
+            assert torch.equal(a[2][n], b[2][n]), n
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    with pytest.raises(RuntimeError):                       # (mode "1" is still set) the text tower's shape check fires in the helper thread
+        model.encode_image_text(img, txt[:, :5])
+
+
 def test_image_lanes_are_bit_identical_to_the_whole_batch(monkeypatch):
     """Inference on a large batch runs as two half batches on two HIP streams (clip/model.py:_image_forward_lanes): the same
     features bit for bit as the whole batch on one stream, for an odd batch size too (encode_image_text keeps the image batch whole:

@@ -259,3 +259,39 @@ def test_gemm_tile_lookup_stays_flat_over_many_row_counts():
     finally:
         ops._TUNED.clear(); ops._TUNED.update(saved)
         ops._DERIVED.clear(); ops._DERIVED.update(saved_d)
+
+
+def test_duet_takes_strict_turns_and_propagates_errors():
+    """cclip_hip/duet.py: two launch sequences in two threads alternate exactly at their interleave points (the first one
+    starts), a paused party lets the other run on, results come back in order and an exception of either side is re-raised."""
+    from cclip_hip import duet
+    log = []
+
+    def seq(tag, n, pause_at=None):
+        def f():
+            for i in range(n):
+                duet.interleave_point()
+                if i == pause_at:
+                    duet.pause()
+                    import time
+                    time.sleep(0.05)                # (a blocking read-back: the other side keeps going meanwhile)
+                    duet.resume()
+                log.append((tag, i))
+            return tag
+        return f
+
+    assert duet.run(seq("a", 3), seq("b", 5)) == ("a", "b")
+    assert log[:6] == [("a", 0), ("b", 0), ("a", 1), ("b", 1), ("a", 2), ("b", 2)] and log[6:] == [("b", 3), ("b", 4)]
+    log.clear()
+    duet.run(seq("a", 4), seq("b", 2, pause_at=0))
+    assert [t for t in log if t[0] == "a"] == [("a", i) for i in range(4)] and log.index(("a", 3)) < log.index(("b", 0))
+    duet.interleave_point(); duet.pause(); duet.resume()            # no-ops outside run()
+
+    def boom():
+        duet.interleave_point()
+        raise ValueError("from the helper thread")
+    import pytest
+    with pytest.raises(ValueError):
+        duet.run(seq("a", 3), boom)
+    with pytest.raises(ValueError):
+        duet.run(boom, seq("b", 3))
