@@ -24,10 +24,16 @@ __global__ __launch_bounds__(256, 1) void gemm_a4w_kernel(const GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + 255) / 256;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  // split_major (= tiles per split): ONE grid dimension of splits x tiles, the work list ordered split by split and cut into one
+  // contiguous run per XCD (xcd_remap) - an XCD then works on one or two splits, i.e. one or two token ranges, and its L2 fetches
+  // those ranges of both operands once for all the output tiles that contract over them.  (tiles, splits) as a 2-D grid deals
+  // every split's tiles to all eight XCDs: each L2 then pulls every token range.
+  const int item = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = p.split_major ? item % p.split_major : item;
+  const int zid = p.split_major ? item / p.split_major : (int)blockIdx.y;
   const int bm0 = (bid / tiles_n) * 256, bn0 = (bid % tiles_n) * 256;
   const int nkt = p.K / BK;
-  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt0 = zid * p.ktiles_per_split;
   const int kt1 = (kt0 + p.ktiles_per_split < nkt) ? kt0 + p.ktiles_per_split : nkt;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, g = lane >> 4;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a4w_kernel(const GemmArgs p) {
     for (int mt = 0; mt < 8; ++mt) {
       const int m = bm0 + wm * 128 + 16 * mt + li;
       if (m < p.M) {
-        if (p.split_ws) p.colsum_ws[(long)blockIdx.y * p.M + m] = accb[mt][0];
+        if (p.split_ws) p.colsum_ws[(long)zid * p.M + m] = accb[mt][0];
         else p.colsum_dst[m] = (p.colsum_acc ? p.colsum_dst[m] : 0.f) + accb[mt][0];
       }
     }
@@ -120,6 +126,12 @@ bool cclip_gemm_launch_cfg11(int lay, int act, dim3 grid, hipStream_t stream, co
   const int nkt = a.K / BK;
   const int last = nkt - (int)(grid.y - 1) * a.ktiles_per_split;          // K-tiles of the last split
   if (a.ktiles_per_split < 2 || last < 2) return false;
+  if (grid.y > 1 && !(a.dbg & 32)) {                                       // split-major XCD placement (dbg bit 5: the 2-D grid of round 3's first form)
+    GemmArgs b = a;
+    b.split_major = (int)grid.x;
+    hipLaunchKernelGGL(gemm_a4w_kernel, dim3(grid.x * grid.y), dim3(256), 0, stream, b);
+    return true;
+  }
   hipLaunchKernelGGL(gemm_a4w_kernel, grid, dim3(256), 0, stream, a);
   return true;
 }

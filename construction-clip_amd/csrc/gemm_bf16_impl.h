@@ -35,6 +35,7 @@ struct GemmArgs {
   // configurations 8 / 10: LayerNorm folded into the projection (cclip_hip.h): (mean, rstd) per row, column sums of the scaled weight;
   // the residual form's extra outputs for the next folded projection
   const float* ln_stats = nullptr; const float* ln_c1 = nullptr; float* rowstats = nullptr;
+  int split_major = 0;   // configuration 11: tiles per split when the grid is ONE dimension of splits x tiles walked split-major (0: grid = (tiles, splits))
   int group_n = 0;    // tile order: 0 = row-major over (row tile, column tile); G > 0 = column groups of G tiles, row-major inside a group (tile_coords)
   int dbg = 0;        // timing ablations of configurations 8 / 10 (CCLIP_GEMM_DBG; bit 0: no epilogue) - never set by the product path
 };
@@ -361,7 +362,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
         if (p.split_ws) {
-          float* o = p.split_ws + ((long)blockIdx.y * p.M + m) * p.N + n0;
+          float* o = p.split_ws + ((long)(p.split_major ? xcd_remap(blockIdx.x, gridDim.x) / p.split_major : (int)blockIdx.y) * p.M + m) * p.N + n0;
           *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
           if (n0 + 4 < p.N) *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
           continue;

@@ -18,7 +18,10 @@ for name, M, N, K in [("img wgrad qkv", 2304, 768, 51200), ("img wgrad out", 768
     rows = []
     for cfg in (2, 3, 11):
         tiles = -(-M // 256) * -(-N // (128 if cfg == 2 else 256))
-        for sp in sorted({min(32, max(1, 256 // tiles)), min(32, max(1, 512 // tiles)), min(32, max(1, 768 // tiles)), min(32, max(1, 1024 // tiles))}):   # (ws holds 32 slabs)
+        sps = {min(32, max(1, 256 // tiles)), min(32, max(1, 512 // tiles)), min(32, max(1, 768 // tiles)), min(32, max(1, 1024 // tiles))}   # (ws holds 32 slabs)
+        if cfg == 11:
+            sps |= {8, 16}
+        for sp in sorted(sps):
             d = GemmDesc()
             d.A, d.B, d.a_kcontig, d.b_kcontig, d.lda, d.ldb = A.data_ptr(), B.data_ptr(), 0, 0, M, N
             d.M, d.N, d.K, d.alpha, d.ldc, d.split_k, d.tile_config = M, N, K, 1.0, N, sp, cfg
@@ -36,5 +39,7 @@ for name, M, N, K in [("img wgrad qkv", 2304, 768, 51200), ("img wgrad out", 768
                 e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / 4 * 1e3)
             rows.append((statistics.median(ts), cfg, sp))
     fl = 2.0 * M * N * K
+    if "-v" in sys.argv:
+        print("   " + "  ".join(f"cfg{c}/s{sp}: {t:6.1f}" for t, c, sp in sorted(rows, key=lambda r: (r[1], r[2]))))
     best = {c: min((r for r in rows if r[1] == c), default=None) for c in (2, 3, 11)}
     print(f"{name:15s} " + "  ".join(f"cfg{c}: {b[0]:7.1f} us (split {b[2]:2d}) {fl / b[0] * 1e-6 / PEAK:5.3f}" for c, b in best.items() if b), flush=True)
