@@ -173,6 +173,7 @@ struct Fp8Args {
   bf16* out; long ldc;                                                // OUT 0: 16-bit
   unsigned char* out8; long ldo8; unsigned char* out_mx; long ldomx;  // OUT 1: e4m3 + E8M0 per 32 output columns
   float* out_f32; const float* residual; long ldf;                    // OUT 2: fp32, + residual (same leading dimension)
+  int group_n;                                                        // tile order: column groups of this many tiles (tile_coords); 0 = row-major
   int dbg;                                                            // timing ablation (CCLIP_FP8_DBG bit 0: no epilogue); never set by the product path
 };
 
@@ -222,7 +223,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const Fp8Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN_ - 1) / BN_;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bm0 = (bid / tiles_n) * BM_, bn0 = (bid % tiles_n) * BN_;
+  int tm_i, tn_i;
+  tile_coords(bid, (p.M + BM_ - 1) / BM_, tiles_n, p.group_n, tm_i, tn_i);
+  const int bm0 = tm_i * BM_, bn0 = tn_i * BN_;
   const int nkt = (p.K + KB - 1) / KB;
   const int wm = wave / WN, wn = wave % WN;
   const int wm0 = wm * 16 * MT, wn0 = wn * 64;
@@ -556,6 +559,14 @@ extern "C" int CCLIP_FN(cclip_gemm_fp8_ex)(const cclip_fp8_gemm_desc* d, hipStre
   a.out8 = (unsigned char*)d->out_fp8; a.ldo8 = d->ld_out_fp8; a.out_mx = (unsigned char*)d->out_block_scale; a.ldomx = d->ld_out_block_scale;
   a.out_f32 = d->out_f32; a.residual = d->residual; a.ldf = d->ldf;
   { static const int dbg = getenv("CCLIP_FP8_DBG") ? atoi(getenv("CCLIP_FP8_DBG")) : 0; a.dbg = dbg; }
+  {
+    // tile order (gemm_bf16_impl.h tile_coords): which weight panels one XCD's L2 holds together.  Measured per column-tile count
+    // on the ViT-L/14@336px shapes (profiles/r03_tile_order_ab.txt): 4 column tiles (N = 1024) -11 % / -4 % in groups of 3,
+    // 16 column tiles (N = 4096) -2 % in groups of 8, 12 column tiles nothing.  CCLIP_FP8_GROUP_N overrides (0 = row-major).
+    static const int gn_env = getenv("CCLIP_FP8_GROUP_N") ? atoi(getenv("CCLIP_FP8_GROUP_N")) : -1;
+    const int tn = (d->N + 255) / 256;
+    a.group_n = gn_env >= 0 ? gn_env : (tn == 4 ? 3 : tn >= 16 ? 8 : 0);
+  }
   const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
   dim3 grid(tiles), block(512);
 #define FP8L(ACTV, MXAV, OUTV) hipLaunchKernelGGL((gemm_fp8_kernel<ACTV, MXAV, OUTV>), grid, block, 0, stream, a)
