@@ -339,8 +339,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const Fp8Args p) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // the row scales of all eight m-tiles up front: a load inside the loop is waited for with vmcnt(0), and on this chip that
+    // also waits for every store issued before it - each m-tile's stores then complete before the next m-tile starts
+    float samv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) samv[mt] = MXA ? 1.0f : p.sa[bm0 + wm0 + 16 * mt + li];
     auto values = [&](int mt, int h, float (&v)[8]) {
-      const float sam = MXA ? 1.0f : p.sa[bm0 + wm0 + 16 * mt + li];
+      const float sam = samv[mt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = acc[mt][2 * h][r]; v[4 + r] = acc[mt][2 * h + 1][r]; }
 #pragma unroll
@@ -407,11 +412,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const Fp8Args p) {
     // stored as 16 bytes per lane = one instruction of 16 rows x 64 contiguous bytes (was two of 16 rows x 32 bytes, 8 per lane)
     char* patch = smem + wave * 16384;
     const int r16 = lane >> 2, c4 = lane & 3;
+    float samv[MT];                                    // (up front: see the 16-bit path)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) samv[mt] = MXA ? 1.0f : p.sa[bm0 + wm0 + 16 * mt + li];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       char* buf = patch + (mt & 1) * 1024;
       const int m = bm0 + wm0 + 16 * mt + li;
-      const float sam = MXA ? 1.0f : p.sa[m];
+      const float sam = samv[mt];
       int eb[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
