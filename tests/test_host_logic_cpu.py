@@ -213,6 +213,17 @@ def test_gemm_tile_lookup_takes_the_nearest_token_count(monkeypatch):
         assert ops._nearest_tuned("bfloat16|45000|1536|768|1|1|0|0|1|0|0|1|1|0|0") is None    # another K
         assert ops._nearest_tuned("bfloat16|51201|768|768|1|1|0|1|0|0|1|1|1|0|0") == (3, 1)   # configuration 4 needs M % 256 == 0
         assert ops._nearest_tuned("bfloat16|25600|768|768|1|1|0|1|0|0|1|1|1|0|0") == (4, 1)
+        # the tile ORDER rides in bits 8..15 of the configuration: handed on with the entry, and kept when the hand-scheduled
+        # configuration itself has to be replaced (a contraction that is not whole 64-deep K-tiles)
+        fc = "bfloat16|%d|3072|%d|1|1|0|0|1|0|0|1|1|0|0"
+        ops._TUNED[fc % (51200, 768)] = (8 + 256 * 4, 1)
+        ops._TUNED[fc % (51200, 200)] = (8 + 256 * 6, 1)
+        assert ops._nearest_tuned(fc % (25600, 768)) == (8 + 256 * 4, 1)
+        assert ops._nearest_tuned(fc % (25600, 200)) == (3 + 256 * 6, 1)
+        wg11 = "bfloat16|768|3072|%d|0|0|0|1|0|0|0|0|-1|1|0"
+        ops._TUNED[wg11 % 51200] = (11, 7)
+        assert ops._nearest_tuned(wg11 % 25600) == (11, 4)                                  # scaled split, still whole K-tiles
+        assert ops._nearest_tuned(wg11 % 25000) == (2, 3)                                   # 25000 % 64 != 0: the 8-wave kernel
         monkeypatch.setenv("CCLIP_TUNE_EXACT", "1")
         assert ops._nearest_tuned(fwd % 45000) is None
     finally:
